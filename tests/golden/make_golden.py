@@ -1,0 +1,555 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Run ONLY in the authoring container (``/root/reference`` is absent on the GPU
+box; the fixtures are what travels):
+
+    python tests/golden/make_golden.py
+
+The reference's hot path imports CuPy / cuCIM / cuVS at module top, none of
+which exist here.  Following the reference's own test technique
+(``tests/test_illumination_correction.py:51``,
+``tests/test_optimization_codeword_exclusions.py:142-145``) the script installs
+stand-in modules in ``sys.modules`` - ``cupy`` forwards to NumPy,
+``cupyx.scipy.ndimage`` to SciPy, ``cuvs...pairwise_distance`` to an expanded
+float32 distance - and then imports and *executes the reference's own code*.
+What the fixtures pin is therefore the reference's control flow and semantics
+with NumPy/SciPy arithmetic: integer outputs exactly, floats to ~1e-5
+(cuRAND streams, cuFFT rounding and cuVS summation order are not reproducible
+off NVIDIA hardware; see DESIGN.md "Oracle pinning").
+
+No reference source is copied: only inputs and the outputs it produced are
+saved.
+"""
+
+from __future__ import annotations
+
+import sys
+import types
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import pandas as pd
+import scipy.ndimage as sndi
+
+HERE = Path(__file__).resolve().parent
+REF_SRC = Path("/root/reference/src")
+
+
+# ----------------------------------------------------------------------------
+# stand-in modules
+# ----------------------------------------------------------------------------
+class _NullCtx:
+    id = 0
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def use(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+class _Pool:
+    def free_all_blocks(self):
+        pass
+
+
+def _expanded_euclidean(x, y, metric="euclidean", out=None):
+    """cuVS 'euclidean' = expanded sqrt(max(0, |x|^2 + |y|^2 - 2 x.y)) in float32."""
+    x = np.asarray(x, dtype=np.float32)
+    y = np.asarray(y, dtype=np.float32)
+    xn = np.sum(x * x, axis=1, dtype=np.float32)[:, None]
+    yn = np.sum(y * y, axis=1, dtype=np.float32)[None, :]
+    d2 = xn + yn - np.float32(2.0) * (x @ y.T)
+    d = np.sqrt(np.maximum(d2, np.float32(0.0))).astype(np.float32)
+    if out is not None:
+        out[...] = d
+        return out
+    return d
+
+
+def install_standins() -> None:
+    cp = types.ModuleType("cupy")
+
+    def _getattr(name):
+        return getattr(np, name)
+
+    cp.__getattr__ = _getattr  # type: ignore[attr-defined]
+    cp.asnumpy = np.asarray
+    cp.get_array_module = lambda *a: np
+    cp.ElementwiseKernel = lambda *a, **k: (
+        lambda recon, ht, cons: np.where(cons < 0, recon, recon * ht).astype(np.float32)
+    )
+    cp.cuda = SimpleNamespace(
+        Device=_NullCtx,
+        Stream=SimpleNamespace(null=_NullCtx()),
+        memory=SimpleNamespace(OutOfMemoryError=type("OutOfMemoryError", (Exception,), {})),
+        runtime=SimpleNamespace(getDeviceCount=lambda: 1),
+    )
+    cp.get_default_memory_pool = lambda: _Pool()
+    cp.get_default_pinned_memory_pool = lambda: _Pool()
+    fft = types.ModuleType("cupy.fft")
+    fft.rfftn = np.fft.rfftn
+    fft.irfftn = np.fft.irfftn
+    fft.fftn = np.fft.fftn
+    fft.ifftn = np.fft.ifftn
+    fft.ifftshift = np.fft.ifftshift
+    fft.fftshift = np.fft.fftshift
+    fft.config = SimpleNamespace(
+        get_plan_cache=lambda: SimpleNamespace(clear=lambda: None)
+    )
+    cp.fft = fft
+    cp.random = np.random
+    cp.linalg = np.linalg
+    cp.ndarray = np.ndarray
+    sys.modules["cupy"] = cp
+    sys.modules["cupy.fft"] = fft
+
+    cupyx = types.ModuleType("cupyx")
+    cupyx_scipy = types.ModuleType("cupyx.scipy")
+    cupyx_ndi = types.ModuleType("cupyx.scipy.ndimage")
+    for name in ("gaussian_filter", "affine_transform", "map_coordinates"):
+        setattr(cupyx_ndi, name, getattr(sndi, name))
+    cupyx_scipy.ndimage = cupyx_ndi
+    cupyx.scipy = cupyx_scipy
+    sys.modules["cupyx"] = cupyx
+    sys.modules["cupyx.scipy"] = cupyx_scipy
+    sys.modules["cupyx.scipy.ndimage"] = cupyx_ndi
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    def _absent(*a, **k):
+        raise RuntimeError("third-party routine not available in this container")
+
+    _mod("cucim")
+    _mod("cucim.skimage")
+    _mod("cucim.skimage.measure", label=_absent, regionprops_table=_absent)
+    _mod("cucim.skimage.morphology", remove_small_objects=_absent)
+    _mod("cucim.skimage.registration", phase_cross_correlation=_absent)
+    _mod("cuvs")
+    _mod("cuvs.distance", pairwise_distance=_expanded_euclidean)
+    _mod("roifile", roiread=_absent)
+    _mod("rtree")
+    _mod("shapely")
+    _mod("shapely.geometry", Point=object, Polygon=object)
+    _mod("skimage")
+    _mod("skimage.draw", polygon=_absent)
+    _mod("skimage.measure", regionprops_table=_absent)
+
+
+def import_reference():
+    install_standins()
+    sys.path.insert(0, str(REF_SRC))
+    import importlib
+
+    rl = importlib.import_module("merfish3danalysis.utils.rlgc")
+    mv = importlib.import_module("merfish3danalysis.utils.multiview_registration")
+    dw = importlib.import_module("merfish3danalysis.utils.decode_warping")
+    sf = importlib.import_module("merfish3danalysis.utils.sofima_registration")
+    pdm = importlib.import_module("merfish3danalysis.PixelDecoder")
+    return rl, mv, dw, sf, pdm
+
+
+# ----------------------------------------------------------------------------
+# synthetic inputs (shared with the tests through the saved arrays)
+# ----------------------------------------------------------------------------
+def gaussian_psf(shape, sigma):
+    zz, yy, xx = np.meshgrid(
+        *[np.arange(s, dtype=np.float64) - (s // 2) for s in shape], indexing="ij"
+    )
+    psf = np.exp(
+        -0.5 * ((zz / sigma[0]) ** 2 + (yy / sigma[1]) ** 2 + (xx / sigma[2]) ** 2)
+    )
+    return (psf / psf.sum()).astype(np.float32)
+
+
+def phantom(shape, n_spots, seed, psf, background=20.0, amp=(400.0, 1500.0)):
+    rng = np.random.default_rng(seed)
+    vol = np.zeros(shape, dtype=np.float64)
+    for _ in range(n_spots):
+        z, y, x = (rng.integers(0, s) for s in shape)
+        vol[z, y, x] += rng.uniform(*amp)
+    blurred = sndi.convolve(vol, psf.astype(np.float64), mode="reflect") * psf.size ** 0
+    noisy = rng.poisson(blurred * 40.0 + background)
+    return np.clip(noisy, 0, 65535).astype(np.uint16)
+
+
+def hw4_codebook(n_bits: int, n_codes: int, seed: int, n_blank: int = 10):
+    """Greedy weight-4, Hamming-distance-4 codebook as a DataFrame (gene_id + bits)."""
+    import itertools
+
+    rng = np.random.default_rng(seed)
+    combos = list(itertools.combinations(range(n_bits), 4))
+    rng.shuffle(combos)
+    chosen = []
+    for c in combos:
+        s = set(c)
+        if all(len(s & set(o)) <= 2 for o in chosen):
+            chosen.append(c)
+        if len(chosen) == n_codes:
+            break
+    mat = np.zeros((len(chosen), n_bits), dtype=np.int64)
+    for i, c in enumerate(chosen):
+        mat[i, list(c)] = 1
+    names = [f"gene{i:03d}" for i in range(len(chosen) - n_blank)] + [
+        f"Blank-{i:02d}" for i in range(n_blank)
+    ]
+    df = pd.DataFrame(mat, columns=[f"bit{i + 1:02d}" for i in range(n_bits)])
+    df.insert(0, "gene_id", names)
+    return df
+
+
+# ----------------------------------------------------------------------------
+# fixtures
+# ----------------------------------------------------------------------------
+def make_rlgc(rl):
+    cases = {
+        "rlgc_a": dict(shape=(12, 40, 44), psf_shape=(7, 9, 9), sigma=(1.4, 1.6, 1.6), seed=3, n=25),
+        "rlgc_b": dict(shape=(16, 64, 64), psf_shape=(9, 11, 11), sigma=(1.8, 1.6, 1.6), seed=4, n=60),
+    }
+    for name, c in cases.items():
+        psf = gaussian_psf(c["psf_shape"], c["sigma"])
+        img = phantom(c["shape"], c["n"], c["seed"], psf)
+        out = rl.chunked_rlgc(img, psf, crop_yx=2048, rng_seed=42, release_memory=False)
+        padded, pad_width = rl.pad_for_linear_fft(img, psf.shape)
+        np.savez_compressed(
+            HERE / f"{name}.npz",
+            image=img,
+            psf=psf,
+            output=out.astype(np.float32),
+            pad_width=np.asarray(pad_width, dtype=np.int64),
+            padded_shape=np.asarray(padded.shape, dtype=np.int64),
+            padded_psf=rl.pad_psf(psf, padded.shape).astype(np.float32),
+        )
+        print(name, out.shape, float(out.sum()) / float(img.sum()))
+    # tiled route: crop smaller than the image -> per-tile seeds and halos
+    psf = gaussian_psf((5, 7, 7), (1.2, 1.3, 1.3))
+    img = phantom((8, 40, 56), 30, 5, psf)
+    out = rl.chunked_rlgc(img, psf, crop_yx=24, rng_seed=7, release_memory=False)
+    np.savez_compressed(
+        HERE / "rlgc_tiled.npz", image=img, psf=psf, output=out.astype(np.float32),
+        crop_yx=np.int64(24), rng_seed=np.int64(7),
+    )
+    # 2-D input promoted to one z plane
+    psf2 = gaussian_psf((1, 9, 9), (1.0, 1.5, 1.5))[0]
+    img2 = phantom((1, 48, 48), 12, 6, psf2[None])[0]
+    out2 = rl.chunked_rlgc(img2, psf2, rng_seed=42, release_memory=False)
+    np.savez_compressed(HERE / "rlgc_2d.npz", image=img2, psf=psf2, output=out2.astype(np.float32))
+    # helper vectors
+    sizes = np.arange(1, 2200, dtype=np.int64)
+    np.savez_compressed(
+        HERE / "rlgc_geometry.npz",
+        sizes=sizes,
+        next_size=np.asarray([rl.next_gpu_fft_size(int(s)) for s in sizes]),
+        pad_cases=np.asarray(
+            [
+                (l, p, *rl._axis_linear_fft_padding(l, p))
+                for l in (1, 16, 64, 100, 256, 2048)
+                for p in (1, 7, 16, 51, 64)
+            ],
+            dtype=np.int64,
+        ),
+    )
+
+
+def _bare_decoder(pdm, codebook_df, n_bits, is_3d=True):
+    dec = pdm.PixelDecoder.__new__(pdm.PixelDecoder)
+    dec._datastore = SimpleNamespace(codebook=codebook_df)
+    dec._n_merfish_bits = n_bits
+    dec._verbose = 0
+    dec._is_3D = is_3d
+    dec._load_codebook()
+    dec._excluded_gene_ids, dec._excluded_codeword_indices = dec._resolve_excluded_gene_ids(None)
+    dec._decoding_matrix_no_errors = dec._normalize_codebook(include_errors=False)
+    dec._decoding_matrix = dec._decoding_matrix_no_errors.copy()
+    dec._iterative_normalization_loaded = False
+    dec._global_normalization_loaded = False
+    return dec
+
+
+def synth_bit_stack(codebook_df, n_bits, shape, n_spots, seed):
+    """f32[B,Z,Y,X] 'readout x predictor' stack with coded spots + background."""
+    rng = np.random.default_rng(seed)
+    mat = codebook_df.iloc[:, 1 : n_bits + 1].to_numpy(dtype=np.int64)
+    stack = rng.gamma(2.0, 15.0, size=(n_bits, *shape))
+    truth = []
+    for _ in range(n_spots):
+        code = int(rng.integers(0, mat.shape[0]))
+        z, y, x = (int(rng.integers(1, s - 1)) for s in shape)
+        amp = rng.uniform(600, 2500)
+        blob = np.zeros(shape)
+        blob[z, y, x] = amp
+        blob = sndi.gaussian_filter(blob, (0.9, 1.3, 1.3)) * 12.0
+        for b in np.nonzero(mat[code])[0]:
+            stack[b] += blob * rng.uniform(0.7, 1.3)
+        truth.append((code, z, y, x))
+    return stack.astype(np.float32), np.asarray(truth, dtype=np.int64)
+
+
+def make_decode(pdm):
+    for name, n_bits, n_codes, shape, seed, excl in (
+        ("decode_pixels_16", 16, 140, (6, 48, 52), 11, None),
+        ("decode_pixels_22", 22, 140, (4, 40, 64), 12, ("gene003", "gene010")),
+    ):
+        cb = hw4_codebook(n_bits, n_codes, seed)
+        dec = _bare_decoder(pdm, cb, n_bits)
+        if excl:
+            dec._excluded_gene_ids, dec._excluded_codeword_indices = dec._resolve_excluded_gene_ids(excl)
+        stack, truth = synth_bit_stack(cb, n_bits, shape, 40, seed)
+        # reference low-pass under the SciPy stand-in
+        dec._image_data = stack
+        dec._lp_filter(sigma=(3.0, 1.0, 1.0))
+        lp = dec._image_data_lp.copy()
+        rng = np.random.default_rng(seed + 100)
+        bkd = rng.uniform(5, 40, size=n_bits).astype(np.float32)
+        nrm = rng.uniform(150, 400, size=n_bits).astype(np.float32)
+        dec._global_background_vector = bkd
+        dec._global_normalization_vector = nrm
+        dec._global_normalization_loaded = True
+        mag_thr = (0.9, 10.0)
+        dec._decode_pixels(magnitude_threshold=mag_thr)
+        np.savez_compressed(
+            HERE / f"{name}.npz",
+            codebook_bits=cb.iloc[:, 1 : n_bits + 1].to_numpy(dtype=np.int8),
+            gene_ids=np.asarray(cb["gene_id"].tolist()),
+            stack=stack,
+            truth=truth,
+            lowpass=lp.astype(np.float32),
+            background=bkd,
+            normalization=nrm,
+            magnitude_threshold=np.asarray(mag_thr, dtype=np.float64),
+            pixel_threshold=np.float64(dec._pixel_assignment_threshold),
+            transcript_threshold=np.float64(dec._transcript_distance_threshold),
+            excluded_indices=np.asarray(dec._excluded_codeword_indices, dtype=np.int64),
+            decoding_matrix=np.asarray(dec._decoding_matrix, dtype=np.float64),
+            decoded=dec._decoded_image,
+            magnitude=dec._magnitude_image,
+            distance=dec._distance_image,
+            scaled=dec._scaled_pixel_images,
+            blank_count=np.int64(dec._blank_count),
+        )
+        print(name, "decoded px:", int((dec._decoded_image >= 0).sum()))
+    # un-normalised decode ("none") on a small stack, 2-D low-pass mode
+    cb = hw4_codebook(16, 60, 21)
+    dec = _bare_decoder(pdm, cb, 16, is_3d=False)
+    stack, _ = synth_bit_stack(cb, 16, (3, 32, 36), 12, 21)
+    stack /= np.float32(300.0)
+    dec._image_data = stack
+    dec._lp_filter(sigma=(3.0, 1.0, 1.0))
+    lp2 = dec._image_data_lp.copy()
+    dec._decode_pixels(magnitude_threshold=(0.7, 10.0))
+    np.savez_compressed(
+        HERE / "decode_pixels_2d_none.npz",
+        codebook_bits=cb.iloc[:, 1:17].to_numpy(dtype=np.int8),
+        stack=stack,
+        lowpass=lp2,
+        decoded=dec._decoded_image,
+        magnitude=dec._magnitude_image,
+        distance=dec._distance_image,
+        scaled=dec._scaled_pixel_images,
+        pixel_threshold=np.float64(dec._pixel_assignment_threshold),
+        decoding_matrix=np.asarray(dec._decoding_matrix, dtype=np.float64),
+    )
+    # _warp_pixel known-answer (tests/test_pixeldecoder_coordinates.py:6-41)
+    pixel = np.array([10.0, 20.0, 30.0], dtype=np.float32)
+    spacing = np.array([0.32, 0.098, 0.098], dtype=np.float32)
+    origin = np.array([2761.3, 107.81, 0.0], dtype=np.float32)
+    c2s = np.array([[1, 0, 0, 0], [0, -0.07, -1, 0], [0, -1, 0.07, 0], [0, 0, 0, 1]], dtype=np.float32)
+    ga = np.array([[1, 0, 0, 0.5], [0, 1, 0, 1.25], [0, 0, 1, -2.0], [0, 0, 0, 1]], dtype=np.float32)
+    np.savez_compressed(
+        HERE / "warp_pixel.npz", pixel=pixel, spacing=spacing, origin=origin,
+        camera_to_stage=c2s, affine=ga,
+        expected=pdm.PixelDecoder._warp_pixel(pixel, spacing, origin, ga, c2s),
+        expected_no_camera=pdm.PixelDecoder._warp_pixel(pixel, spacing, origin, ga, None),
+    )
+
+
+class _FakeStore:
+    """Duck-typed datastore for the normalisation fixtures (identity transforms)."""
+
+    def __init__(self, readouts, predictors, n_bits):
+        self._r, self._p = readouts, predictors
+        self.tile_ids = [f"tile{i:04d}" for i in range(readouts.shape[0])]
+        self.bit_ids = [f"bit{i + 1:03d}" for i in range(n_bits)]
+        self.round_ids = ["round001"]
+        self.voxel_size_zyx_um = (0.315, 0.098, 0.098)
+        self.saved = {}
+
+    def _t(self, tile):
+        return self.tile_ids.index(tile) if isinstance(tile, str) else int(tile)
+
+    def _b(self, bit):
+        return self.bit_ids.index(bit) if isinstance(bit, str) else int(bit)
+
+    def load_local_readout_image(self, tile, bit, return_future=False):
+        return self._r[self._t(tile), self._b(bit)]
+
+    def load_local_feature_predictor_image(self, tile, bit, return_future=False):
+        return self._p[self._t(tile), self._b(bit)]
+
+    def load_local_wavelengths_um(self, tile, bit):
+        return (0.561, 0.590)
+
+    def load_local_round_linker(self, tile, bit):
+        return 1
+
+    def load_chromatic_affine_transform_zyx_um(self, wavelength_um):
+        return np.eye(4, dtype=np.float32)
+
+    def load_local_sofima_flow_field(self, tile, round, return_future=False):
+        return None
+
+    def save_decode_normalization_vectors(self, key, kind, norm, bkd, **kw):
+        self.saved[kind] = (np.asarray(norm).copy(), np.asarray(bkd).copy())
+
+
+def make_normalization(pdm):
+    n_bits, tiles, shape = 16, 3, (6, 40, 40)
+    rng = np.random.default_rng(31)
+    readouts = rng.gamma(2.0, 60.0, size=(tiles, n_bits, *shape))
+    readouts[0, 2, 3, 5, 5] = 60000.0  # hot pixel (> 50000) (PixelDecoder.py:1072-1074)
+    readouts = np.clip(readouts, 0, 65535).astype(np.uint16)
+    predictors = rng.uniform(0.0, 1.0, size=(tiles, n_bits, *shape)).astype(np.float32)
+    store = _FakeStore(readouts, predictors, n_bits)
+    cb = hw4_codebook(n_bits, 60, 33)
+    dec = _bare_decoder(pdm, cb, n_bits)
+    dec._datastore = store
+    dec._z_slice = slice(0, None)
+    dec._decode_run_key = None
+    dec._effective_decode_mode = "3d"
+    dec._normalization_cell_polygons = []
+    dec._normalization_cell_segmentation_present = False
+    dec._normalization_cell_mask_cache = {}
+    dec._normalization_cell_mask_for_tile = lambda tile_id, image_shape_zyx: None
+    dec._global_normalization_vectors(tile_indices=[0, 1, 2], lowpass_sigma=(3.0, 1.0, 1.0))
+    norm, bkd = store.saved["global"]
+    np.savez_compressed(
+        HERE / "global_normalization.npz", readouts=readouts, predictors=predictors,
+        normalization=norm, background=bkd,
+    )
+    print("global norm", norm[:4], bkd[:4])
+
+    # iterative normalisation from a synthetic barcode table (PixelDecoder.py:1250-1421)
+    rng = np.random.default_rng(41)
+    mat = cb.iloc[:, 1 : n_bits + 1].to_numpy(dtype=np.int64)
+    rows = []
+    for i in range(200):
+        code = int(rng.integers(0, mat.shape[0]))
+        on = np.nonzero(mat[code])[0] + 1
+        row = {"gene_id": cb["gene_id"][code]}
+        for b in range(1, n_bits + 1):
+            base = rng.uniform(0.0, 40.0)
+            row[f"bit{b:02d}_mean_intensity"] = float(np.float16(base + (rng.uniform(150, 500) if b in on else 0.0)))
+        for j, ob in enumerate(on[:4]):
+            row[f"on_bit_{j + 1}"] = int(ob)
+        rows.append(row)
+    df = pd.DataFrame(rows)
+    dec._df_barcodes_loaded = df
+    dec._iterative_background_vector = None
+    dec._iterative_normalization_vector = None
+    dec._global_background_vector = bkd
+    dec._global_normalization_vector = norm
+    dec._optimization_excluded_gene_ids = ()
+    dec._iterative_normalization_vectors()
+    inorm, ibkd = store.saved["iterative"]
+    df.to_json(HERE / "iterative_normalization_barcodes.json", orient="split")
+    np.savez_compressed(
+        HERE / "iterative_normalization.npz", normalization=inorm, background=ibkd,
+        global_normalization=norm, global_background=bkd,
+    )
+    print("iter norm", inorm[:4], ibkd[:4])
+
+
+def make_registration(mv, dw, sf):
+    rng = np.random.default_rng(51)
+    # overlap slices + point transform (pure NumPy in the reference)
+    shapes = [(31, 64, 64), (24, 48, 48), (8, 10, 12)]
+    shifts = [(0.0, 3.2, -4.7), (0.0, -8.0, 7.0), (0.0, 20.0, 0.0), (1.5, -0.4, 0.0), (0.0, 0.0, -12.0)]
+    rows = []
+    for s in shapes:
+        for t in shifts:
+            sl = mv._overlap_slices_after_translation(s, t)
+            rows.append([*s, *t, *([-1] * 6 if sl is None else [v for q in sl for v in (q.start, q.stop)])])
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] += rng.normal(0, 0.01, size=(3, 3)).astype(np.float32)
+    T[:3, 3] = (0.63, -0.4, 1.2)
+    pts = rng.uniform(0, 40, size=(17, 3)).astype(np.float32)
+    spacing = (0.315, 0.098, 0.098)
+    # affine warp: u16 in -> u16 out, f32 in -> f32 out (multiview_registration.py:882-892)
+    vol = sndi.gaussian_filter(rng.uniform(0, 1, size=(10, 36, 40)), 1.5)
+    vol = ((vol - vol.min()) / (vol.max() - vol.min()) * 4000).astype(np.float32)
+    warped_f = mv.warp_array_to_reference_gpu(vol, transform_zyx_um=T, spacing_zyx_um=spacing, reference_shape=vol.shape)
+    warped_u = mv.warp_array_to_reference_gpu(vol.astype(np.uint16), transform_zyx_um=T, spacing_zyx_um=spacing, reference_shape=(10, 30, 44))
+    # flow warp
+    flow = rng.normal(0, 1.2, size=(3, 3, 5, 6)).astype(np.float32)
+    stride = (4.0, 8.0, 8.0)
+    box = (4.0, 4.0, 2.0)
+    fw_const = mv.warp_array_to_reference_with_affine_and_sofima_flow_gpu(
+        vol, transform_zyx_um=T, spacing_zyx_um=spacing, reference_shape=vol.shape,
+        sofima_flow_field_xyz_px=flow, flow_field_stride_zyx_px=stride, flow_field_box_start_xyz_px=box)
+    fw_near = mv.warp_array_to_reference_with_affine_and_sofima_flow_gpu(
+        vol, transform_zyx_um=np.eye(4, dtype=np.float32), spacing_zyx_um=(1.0, 1.0, 1.0), reference_shape=vol.shape,
+        sofima_flow_field_xyz_px=flow, flow_field_stride_zyx_px=stride, flow_field_box_start_xyz_px=box, mode="nearest")
+    chrom = np.eye(4, dtype=np.float32)
+    chrom[:3, :3] *= np.float32(1.002)
+    chrom[:3, 3] = (0.01, -0.03, 0.02)
+    np.savez_compressed(
+        HERE / "registration.npz",
+        overlap_rows=np.asarray(rows, dtype=np.float64),
+        transform=T, points=pts, spacing=np.asarray(spacing, dtype=np.float32),
+        points_ref=mv.transform_points_to_reference(pts, transform_zyx_um=T, spacing_zyx_um=spacing, origin_zyx_um=(1.0, 2.0, 3.0)),
+        volume=vol, warped_f32=warped_f, warped_u16=warped_u,
+        flow=flow, flow_stride=np.asarray(stride), flow_box_start=np.asarray(box),
+        flow_warp_constant=fw_const, flow_warp_nearest=fw_near,
+        chromatic=chrom,
+        composed=dw.compose_decode_warp_transform_zyx_um(round_transform_zyx_um=T, chromatic_transform_zyx_um=chrom),
+    )
+    # SOFIMA glue owned by the reference (pure NumPy parts)
+    cfg = sf.SofimaRegistrationConfig()
+    ps = [sf._resolve_patch_and_step(s, cfg) for s in [(16, 256, 256), (64, 2048, 2048), (3, 20, 500), (31, 64, 64)]]
+    fl = rng.normal(0, 2.0, size=(3, 4, 6, 7)).astype(np.float32)
+    fl[2, 1, 2, 3] = 40.0
+    fl[2, 0, 0, 0] = np.nan
+    stab, meta = sf._stabilize_axial_flow_component(fl, cfg)
+    sparse = fl.copy()
+    sparse[:, rng.uniform(size=fl.shape[1:]) < 0.4] = np.nan
+    a = rng.normal(size=(5, 12, 12)).astype(np.float32)
+    b = a + rng.normal(scale=0.1, size=a.shape).astype(np.float32)
+    np.savez_compressed(
+        HERE / "sofima_glue.npz",
+        patch_step=np.asarray(ps, dtype=np.int64),
+        flow=fl, stabilized=stab,
+        stab_median=np.float64(meta["axial_flow_median_px"]),
+        stab_clipped=np.int64(meta["axial_flow_clipped_vectors"]),
+        stab_valid=np.int64(meta["axial_flow_valid_vectors"]),
+        sparse_flow=sparse, median_init=sf._median_initial_flow_field(sparse),
+        nmse_a=a, nmse_b=b, nmse=np.float64(sf._normalized_mean_squared_error(a, b)),
+    )
+
+
+def main():
+    rl, mv, dw, sf, pdm = import_reference()
+    make_rlgc(rl)
+    make_decode(pdm)
+    make_normalization(pdm)
+    make_registration(mv, dw, sf)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
