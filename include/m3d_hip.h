@@ -1,0 +1,142 @@
+/* m3d_hip.h - C ABI of libm3d_hip.so, the MI355X (gfx950) implementation of the
+ * per-tile preprocess -> decode hot path of QI2lab/merfish3d-analysis.
+ *
+ * The reference has no FFI: its boundary is a Python operator API
+ * (SURVEY.md section 8b).  Each entry point below names the reference
+ * function (file:line under src/merfish3danalysis/) whose device work it
+ * replaces; the Python host layer in merfish3d-analysis_amd/ keeps that
+ * function's name and signature and calls through here.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - volumes are Z,Y,X C-contiguous; shapes are int32[3] in Z,Y,X order;
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream);
+ *    entry points are asynchronous on it unless documented otherwise;
+ *  - return value: M3D_OK (0) or a negative m3d_status; no exceptions, no
+ *    allocation except inside *_plan_create;
+ *  - the caller owns every buffer, including the workspace a plan asks for.
+ */
+#ifndef M3D_HIP_H
+#define M3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum m3d_status {
+    M3D_OK = 0,
+    M3D_ERR_INVALID_ARG = -1,   /* -> ValueError   (rlgc.py:160,844-860; PixelDecoder.py:502) */
+    M3D_ERR_OUT_OF_MEMORY = -2, /* -> MemoryError  (rlgc.py:760-780 OOM fallback)            */
+    M3D_ERR_HIP = -3,           /* -> RuntimeError                                            */
+    M3D_ERR_ROCFFT = -4,        /* -> RuntimeError                                            */
+    M3D_ERR_WORKSPACE = -5,     /* -> ValueError: workspace smaller than the plan needs       */
+    M3D_ERR_UNSUPPORTED = -6    /* -> NotImplementedError                                     */
+} m3d_status;
+
+typedef enum m3d_dtype { M3D_U16 = 0, M3D_F32 = 1, M3D_F16 = 2, M3D_I16 = 3 } m3d_dtype;
+
+int m3d_version(void);
+const char *m3d_status_string(int status);
+/* last HIP / rocFFT error text of the calling thread (host string, never NULL) */
+const char *m3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * RLGC deconvolution  (utils/rlgc.py)
+ * ---------------------------------------------------------------------------------- */
+
+/* next_gpu_fft_size, rlgc.py:72-97 */
+int m3d_next_fft_size(int x);
+/* _axis_linear_fft_padding + pad_for_linear_fft geometry, rlgc.py:100-173.
+ * Outputs: padded shape and the (before, after) pad widths per axis. */
+int m3d_rlgc_geometry(const int32_t image_zyx[3], const int32_t psf_zyx[3], int pad_yx,
+                      int32_t padded_zyx[3], int32_t pad_before[3], int32_t pad_after[3]);
+
+typedef struct m3d_rlgc_plan m3d_rlgc_plan;
+
+typedef struct m3d_rlgc_params {
+    int32_t safe_mode;      /* rlgc.py:630-633: stop when EITHER split KLD rises            */
+    float limit;            /* rlgc.py:716: min updated fraction (0.01)                     */
+    float max_delta;        /* rlgc.py:727: max relative delta threshold (0.001)            */
+    uint64_t seed;          /* rlgc.py:564: split seed (42; +tile_idx when tiled, :983)     */
+    int32_t normalize_psf;  /* rlgc.py:310-312                                              */
+    int32_t max_iterations; /* 0 = unbounded like the reference; >0 is a test/bench bound   */
+} m3d_rlgc_params;
+
+#define M3D_RLGC_TRACE_CAP 512
+typedef struct m3d_rlgc_result {
+    int32_t iterations;  /* completed multiplicative updates (num_iters, rlgc.py:698)      */
+    int32_t stop_reason; /* 1 restore_previous_recon, 2 limit, 3 max_delta, 4 max_iterations */
+    int32_t n_trace;     /* entries valid in the arrays below (<= M3D_RLGC_TRACE_CAP)       */
+    int32_t reserved;
+    double kld_image[M3D_RLGC_TRACE_CAP];          /* rlgc.py:626 */
+    double kld_split1[M3D_RLGC_TRACE_CAP];         /* rlgc.py:627 */
+    double kld_split2[M3D_RLGC_TRACE_CAP];         /* rlgc.py:628 */
+    double updated_fraction[M3D_RLGC_TRACE_CAP];   /* rlgc.py:689 */
+    double max_relative_delta[M3D_RLGC_TRACE_CAP]; /* rlgc.py:692 */
+    double update_min[M3D_RLGC_TRACE_CAP];         /* rlgc.py:690 */
+    double update_max[M3D_RLGC_TRACE_CAP];         /* rlgc.py:691 */
+} m3d_rlgc_result;
+
+/* Creates rocFFT plans for the padded shape (replaces the cuFFT plan cache +
+ * _fft_cache_3d, rlgc.py:36-69, 340-347).  Host-synchronous. */
+int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], int pad_yx,
+                         m3d_rlgc_plan **plan);
+size_t m3d_rlgc_plan_workspace_bytes(const m3d_rlgc_plan *plan);
+int m3d_rlgc_plan_destroy(m3d_rlgc_plan *plan);
+
+/* rlgc(), rlgc.py:497-757: pad -> OTF -> iterate -> crop, everything device resident.
+ *  image            : u16 or f32 [Z,Y,X] (image_dtype = M3D_U16 | M3D_F32)
+ *  psf              : f32 [Zp,Yp,Xp] as given to plan_create
+ *  out              : f32 [Z,Y,X]
+ *  injected_splits  : optional f32 [n_injected, Z,Y,X]; iteration k < n_injected uses
+ *                     row k as split1 instead of the Philox draw (parity hook)
+ *  result_host      : optional host struct filled before return
+ * Blocks the host once per iteration (one 64-byte read-back), returns when done. */
+int m3d_rlgc_run(m3d_rlgc_plan *plan, const void *image, int image_dtype, const float *psf,
+                 float *out, void *workspace, size_t workspace_bytes,
+                 const m3d_rlgc_params *params, const float *injected_splits, int n_injected,
+                 m3d_rlgc_result *result_host, void *stream);
+
+/* Philox split of one iteration, for the parity tests of the sampler itself. */
+int m3d_rlgc_debug_split(const void *image, int image_dtype, int64_t n, uint64_t seed,
+                         int32_t iteration, float *split1, void *stream);
+
+/* clip(0, 65535).astype(uint16) of RLGC output, DataRegistration.py:435, 993-995 */
+int m3d_clip_to_u16(const float *in, uint16_t *out, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decode front end  (PixelDecoder.py)
+ * ---------------------------------------------------------------------------------- */
+
+/* float32(readout) * float32(predictor), PixelDecoder.py:1879-1881 / 1060-1062 */
+int m3d_weight_readout(const uint16_t *readout, const float *predictor, float *out, int64_t n,
+                       void *stream);
+
+/* cupyx gaussian_filter(mode="reflect", truncate=4) per bit, PixelDecoder.py:1948-1980.
+ * is_3d != 0: separable Z,Y,X passes with sigma_zyx; is_3d == 0: each plane with
+ * (sigma_y, sigma_x).  `scratch` is one more f32[Z,Y,X]. in may equal out. */
+int m3d_gaussian_lowpass(const float *in, float *out, float *scratch, const int32_t shape_zyx[3],
+                         const float sigma_zyx[3], int is_3d, void *stream);
+
+/* _decode_pixels, PixelDecoder.py:2523-2643 (+ _scale/_clip/_normalize_pixel_traces
+ * :2354-2468, _calculate_distances :2470-2521, exclusions :863-877) fused in one pass:
+ *  stack       f32 [B, N] (N = Z*Y*X voxels, bit-major planes)
+ *  background, normalization : f32[B] or NULL for un-normalised decoding
+ *  codebook    f32 [C, B] unit-norm codewords
+ *  excluded    int32[n_excluded] codeword indices (may be NULL)
+ * outputs: decoded int16[N]; magnitude, distance f16[N]; scaled f16[B, N];
+ *          optional f32 magnitude/distance before quantisation (may be NULL). */
+int m3d_decode_pixels(const float *stack, int32_t B, int64_t N, const float *background,
+                      const float *normalization, const float *codebook, int32_t C,
+                      float pixel_threshold, float magnitude_lo, float magnitude_hi,
+                      const int32_t *excluded, int32_t n_excluded, int16_t *decoded,
+                      uint16_t *magnitude_f16, uint16_t *distance_f16, uint16_t *scaled_f16,
+                      float *magnitude_f32, float *distance_f32, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3D_HIP_H */

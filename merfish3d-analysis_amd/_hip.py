@@ -1,0 +1,150 @@
+"""ctypes binding of ``csrc/libm3d_hip.so`` - the C ABI declared in ``include/m3d_hip.h``.
+
+PyTorch-ROCm supplies device memory (``tensor.data_ptr()``) and streams
+(``torch.cuda.current_stream().cuda_stream``); every kernel on the hot path
+lives in the shared library.  There is no CPU fallback: if the library is
+missing this module raises at first use.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libm3d_hip.so"
+_lib: ctypes.CDLL | None = None
+
+M3D_U16, M3D_F32, M3D_F16, M3D_I16 = 0, 1, 2, 3
+TRACE_CAP = 512
+
+
+class M3DError(RuntimeError):
+    """Non-zero status from libm3d_hip.so that has no more specific Python type."""
+
+
+class RLGCParams(ctypes.Structure):
+    _fields_ = [
+        ("safe_mode", c_int32),
+        ("limit", c_float),
+        ("max_delta", c_float),
+        ("seed", c_uint64),
+        ("normalize_psf", c_int32),
+        ("max_iterations", c_int32),
+    ]
+
+
+class RLGCResult(ctypes.Structure):
+    _fields_ = [
+        ("iterations", c_int32),
+        ("stop_reason", c_int32),
+        ("n_trace", c_int32),
+        ("reserved", c_int32),
+        ("kld_image", ctypes.c_double * TRACE_CAP),
+        ("kld_split1", ctypes.c_double * TRACE_CAP),
+        ("kld_split2", ctypes.c_double * TRACE_CAP),
+        ("updated_fraction", ctypes.c_double * TRACE_CAP),
+        ("max_relative_delta", ctypes.c_double * TRACE_CAP),
+        ("update_min", ctypes.c_double * TRACE_CAP),
+        ("update_max", ctypes.c_double * TRACE_CAP),
+    ]
+
+
+STOP_REASONS = {0: "", 1: "restore_previous_recon", 2: "limit", 3: "max_delta", 4: "max_iterations"}
+
+_I3 = c_int32 * 3
+_F3 = c_float * 3
+
+_SIGNATURES = {
+    "m3d_version": (c_int, []),
+    "m3d_status_string": (c_char_p, [c_int]),
+    "m3d_last_error": (c_char_p, []),
+    "m3d_next_fft_size": (c_int, [c_int]),
+    "m3d_rlgc_geometry": (c_int, [_I3, _I3, c_int, _I3, _I3, _I3]),
+    "m3d_rlgc_plan_create": (c_int, [_I3, _I3, c_int, POINTER(c_void_p)]),
+    "m3d_rlgc_plan_workspace_bytes": (c_size_t, [c_void_p]),
+    "m3d_rlgc_plan_destroy": (c_int, [c_void_p]),
+    "m3d_rlgc_run": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_size_t,
+         POINTER(RLGCParams), c_void_p, c_int, POINTER(RLGCResult), c_void_p],
+    ),
+    "m3d_rlgc_debug_split": (c_int, [c_void_p, c_int, c_int64, c_uint64, c_int32, c_void_p, c_void_p]),
+    "m3d_clip_to_u16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "m3d_weight_readout": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m3d_gaussian_lowpass": (c_int, [c_void_p, c_void_p, c_void_p, _I3, _F3, c_int, c_void_p]),
+    "m3d_decode_pixels": (
+        c_int,
+        [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
+         c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p],
+    ),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path() -> Path:
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library (after torch, so both share one HIP runtime / rocFFT)."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback."
+            )
+        import torch  # noqa: F401  (loads libamdhip64 / librocfft first; same SONAMEs are reused)
+
+        handle = ctypes.CDLL(str(_LIB_PATH), mode=ctypes.RTLD_GLOBAL)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    """Map the C status codes to the reference's exception types."""
+    if status == 0:
+        return
+    handle = lib()
+    detail = handle.m3d_last_error().decode(errors="replace")
+    text = handle.m3d_status_string(status).decode()
+    msg = f"{what + ': ' if what else ''}{text} ({detail})"
+    if status in (-1, -5):
+        raise ValueError(msg)
+    if status == -2:
+        raise MemoryError(msg + " - out of memory")
+    if status == -6:
+        raise NotImplementedError(msg)
+    raise M3DError(msg)
+
+
+def i3(values) -> ctypes.Array:
+    return _I3(*[int(v) for v in values])
+
+
+def f3(values) -> ctypes.Array:
+    return _F3(*[float(v) for v in values])
+
+
+def ptr(tensor) -> int | None:
+    """Device pointer of a contiguous CUDA(HIP) torch tensor (None passes through)."""
+    if tensor is None:
+        return None
+    if not tensor.is_cuda:
+        raise ValueError("expected a tensor in GPU memory")
+    if not tensor.is_contiguous():
+        raise ValueError("expected a contiguous tensor")
+    return tensor.data_ptr()
+
+
+def current_stream(device=None) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,30 @@
+"""Scratch probe (not a test): RLGC timing on the GPU box.  usage: probe.py Z Y X [iters]"""
+import importlib
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+rl = importlib.import_module("merfish3d-analysis_amd.utils.rlgc")
+Z, Y, X = (int(v) for v in sys.argv[1:4])
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(0)
+img = torch.poisson(torch.rand((Z, Y, X), device=dev, generator=g) * 200 + 50, generator=g).to(torch.uint16)
+pz = min(64, Z)
+zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=dev) - n // 2 for n in (pz, 51, 51)], indexing="ij")
+psf = torch.exp(-0.5 * ((zz / 3.0) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2))
+psf = (psf / psf.sum()).float()
+t0 = time.time()
+out, info = rl.rlgc_device(img, psf, max_iterations=1)
+torch.cuda.synchronize()
+print(f"first call (plan + 1 iter): {time.time() - t0:.2f}s padded={info.padded_shape}", flush=True)
+for n in (iters, 2 * iters):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out, info = rl.rlgc_device(img, psf, max_iterations=n)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"iters={info.iterations} stop={info.stop_reason} wall={dt:.3f}s", flush=True)
+print("mem GB", torch.cuda.max_memory_allocated() / 1e9)

@@ -1,0 +1,144 @@
+"""GPU parity: fused decode kernel, Gaussian low-pass and readout weighting vs the oracle.
+
+Integer outputs (decoded indices) and every float16 result volume are compared bit-for-bit
+against ``oracle.decode_ref`` in ``arith="device"`` mode; the low-pass is a float32 filter
+compared at 2e-6 relative (SciPy accumulates in float64, the kernel in float32)."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import decode_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _run(kernels, lp, g, **kw):
+    return kernels.decode_pixels(_t(lp), _t(g["decoding_matrix"]), float(g["pixel_threshold"]),
+                                 want_f32=True, **kw)
+
+
+@pytest.mark.parametrize("name", ["decode_pixels_16", "decode_pixels_22", "decode_pixels_2d_none"])
+def test_decode_pixels_bit_exact_vs_oracle_and_reference(golden, name):
+    kernels = pkg("kernels")
+    g = golden(name)
+    if "background" in g.files:
+        okw = dict(background=g["background"], normalization=g["normalization"],
+                   excluded_indices=tuple(int(v) for v in g["excluded_indices"]),
+                   magnitude_threshold=tuple(g["magnitude_threshold"]))
+        kkw = dict(background=_t(g["background"]), normalization=_t(g["normalization"]),
+                   excluded_indices=okw["excluded_indices"],
+                   magnitude_threshold=okw["magnitude_threshold"])
+    else:
+        okw = dict(magnitude_threshold=(0.7, 10.0))
+        kkw = dict(magnitude_threshold=(0.7, 10.0))
+    dec, mag, dist, sc, mag32, dist32 = _run(kernels, g["lowpass"], g, **kkw)
+    rdec, rmag, rdist, rsc, rmag32, rdist32 = decode_ref.decode_pixels(
+        g["lowpass"], g["decoding_matrix"], float(g["pixel_threshold"]), arith="device",
+        return_f32=True, **okw)
+    assert np.array_equal(dec.cpu().numpy(), rdec)
+    assert np.array_equal(dec.cpu().numpy(), g["decoded"])          # the reference's own output
+    assert np.array_equal(mag32.cpu().numpy(), rmag32)
+    assert np.array_equal(dist32.cpu().numpy(), rdist32)
+    assert np.array_equal(mag.cpu().numpy().view(np.uint16), rmag.view(np.uint16))
+    assert np.array_equal(dist.cpu().numpy().view(np.uint16), rdist.view(np.uint16))
+    assert np.array_equal(sc.cpu().numpy().view(np.uint16), rsc.view(np.uint16))
+    # float distances within 1e-4 of the reference run (pre-float16 value not stored there:
+    # compare through float16, whose spacing below 1 is <= 4.9e-4)
+    assert np.max(np.abs(dist.cpu().numpy().astype(np.float32) - g["distance"].astype(np.float32))) <= 5e-4
+
+
+def test_decode_pixels_random_traces_ragged_sizes():
+    """N not a multiple of 64, C not a multiple of 32, odd B, all-zero and saturated pixels."""
+    kernels = pkg("kernels")
+    rng = np.random.default_rng(3)
+    for B, C, shape in ((16, 140, (3, 37, 41)), (22, 140, (2, 50, 63)), (21, 33, (1, 9, 13)),
+                        (8, 5, (1, 1, 70)), (32, 200, (2, 31, 33))):
+        bits = np.zeros((C, B), dtype=np.int64)
+        for c in range(C):
+            bits[c, rng.choice(B, size=min(4, B), replace=False)] = 1
+        cb = decode_ref.normalize_codebook(bits)
+        stack = rng.gamma(1.5, 0.25, size=(B, *shape)).astype(np.float32)
+        stack[:, 0, 0, 0] = 0.0                      # zero-norm pixel -> magnitude -1
+        stack[:, 0, 0, 1] = 5.0                      # all bits saturate at the clip
+        on = np.nonzero(bits[C // 2])[0]
+        stack[:, 0, 0, 2] = 0.0
+        stack[on, 0, 0, 2] = 1.0                     # exact codeword -> distance ~0
+        stack[on[:2], 0, 0, 3] = 1.0                 # 2-of-4 tie at the pixel threshold
+        stack[np.setdiff1d(np.arange(B), on[:2]), 0, 0, 3] = 0.0
+        thr, _ = decode_ref.codebook_thresholds(4)
+        excl = (1, C - 1)
+        got = kernels.decode_pixels(_t(stack), _t(cb), thr, (0.3, 3.0), excluded_indices=excl, want_f32=True)
+        ref = decode_ref.decode_pixels(stack, cb, thr, (0.3, 3.0), excluded_indices=excl,
+                                       arith="device", return_f32=True)
+        names = ("decoded", "magnitude", "distance", "scaled", "mag32", "dist32")
+        for nm, a, b in zip(names, got, ref):
+            a = a.cpu().numpy()
+            if a.dtype == np.float16:
+                a, b = a.view(np.uint16), b.view(np.uint16)
+            assert np.array_equal(a, b), (nm, B, C, shape)
+        assert ref[1][0, 0, 0] == -1 and ref[0][0, 0, 0] == -1
+        assert ref[0][0, 0, 2] in (C // 2, -1)
+
+
+def test_decode_pixels_full_plane_is_self_consistent():
+    """One 2048x2048 plane, 22 bits / 140 codewords: permutation invariance + re-run identity."""
+    kernels = pkg("kernels")
+    g = torch.Generator(device=DEV).manual_seed(1)
+    B, C = 22, 140
+    rng = np.random.default_rng(9)
+    bits = np.zeros((C, B), dtype=np.int64)
+    for c in range(C):
+        bits[c, rng.choice(B, size=4, replace=False)] = 1
+    cb = _t(decode_ref.normalize_codebook(bits))
+    stack = torch.rand((B, 1, 2048, 2048), device=DEV, generator=g) ** 3
+    a = kernels.decode_pixels(stack, cb, 0.7653669, (0.5, 10.0))
+    b = kernels.decode_pixels(stack, cb, 0.7653669, (0.5, 10.0))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    perm = torch.randperm(2048 * 2048, device=DEV, generator=g)
+    shuffled = stack.view(B, -1)[:, perm].reshape(B, 1, 2048, 2048).contiguous()
+    c = kernels.decode_pixels(shuffled, cb, 0.7653669, (0.5, 10.0))
+    assert torch.equal(a[0].view(-1)[perm], c[0].view(-1))
+    assert torch.equal(a[2].view(-1)[perm], c[2].view(-1))
+    assert int((a[0] >= 0).sum()) > 0
+
+
+@pytest.mark.parametrize("shape,sigma,is3d", [((6, 48, 52), (3.0, 1.0, 1.0), True),
+                                              ((3, 17, 9), (3.0, 1.0, 1.0), True),
+                                              ((5, 40, 33), (3.0, 1.0, 1.0), False),
+                                              ((9, 21, 30), (1.5, 2.0, 0.7), True),
+                                              ((40, 8, 70), (4.4, 1.0, 1.0), True)])
+def test_gaussian_lowpass_matches_scipy(shape, sigma, is3d):
+    kernels = pkg("kernels")
+    rng = np.random.default_rng(2)
+    vol = rng.gamma(2.0, 100.0, size=shape).astype(np.float32)
+    ref = decode_ref.lowpass(vol[None], sigma, is3d)[0]
+    got = kernels.gaussian_lowpass(_t(vol), sigma, is3d).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-4)
+    # in place
+    t = _t(vol)
+    kernels.gaussian_lowpass(t, sigma, is3d, out=t)
+    assert np.array_equal(t.cpu().numpy(), got)
+
+
+def test_gaussian_lowpass_golden_stack(golden):
+    kernels = pkg("kernels")
+    g = golden("decode_pixels_22")
+    for b in (0, 7, 21):
+        got = kernels.gaussian_lowpass(_t(g["stack"][b]), (3.0, 1.0, 1.0), True).cpu().numpy()
+        np.testing.assert_allclose(got, g["lowpass"][b], rtol=2e-6, atol=2e-4)
+
+
+def test_weight_readout_exact():
+    kernels = pkg("kernels")
+    rng = np.random.default_rng(4)
+    r = rng.integers(0, 65536, size=(3, 19, 23)).astype(np.uint16)
+    p = rng.uniform(0, 1, size=r.shape).astype(np.float32)
+    got = kernels.weight_readout(_t(r), _t(p)).cpu().numpy()
+    assert np.array_equal(got, r.astype(np.float32) * p)

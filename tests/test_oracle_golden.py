@@ -1,0 +1,116 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Bit-exact where the reference ran with NumPy arithmetic."""
+
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import decode_ref, philox, rlgc_ref
+
+
+@pytest.mark.parametrize("name", ["rlgc_a", "rlgc_b"])
+def test_rlgc_fullframe_matches_reference_bitwise(golden, name):
+    g = golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out, info = rlgc_ref.rlgc(g["image"], g["psf"], return_info=True)
+    assert info.padded_shape == tuple(g["padded_shape"])
+    assert np.array_equal(np.asarray(info.pad_width), g["pad_width"])
+    assert np.array_equal(out, g["output"])
+    assert np.array_equal(rlgc_ref.pad_psf(g["psf"], info.padded_shape), g["padded_psf"])
+    # flux doubling of the reference update
+    assert abs(out.sum() / g["image"].sum() - 2.0) < 0.02
+
+
+def test_rlgc_tiled_and_2d_routes(golden):
+    g = golden("rlgc_tiled")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = rlgc_ref.chunked_rlgc(g["image"], g["psf"], crop_yx=int(g["crop_yx"]),
+                                    rng_seed=int(g["rng_seed"]))
+        g2 = golden("rlgc_2d")
+        out2 = rlgc_ref.chunked_rlgc(g2["image"], g2["psf"])
+    assert np.array_equal(out, g["output"])
+    assert out2.shape == g2["image"].shape and np.array_equal(out2, g2["output"])
+
+
+def test_rlgc_geometry_vectors(golden):
+    g = golden("rlgc_geometry")
+    assert [rlgc_ref.next_gpu_fft_size(int(s)) for s in g["sizes"]] == list(g["next_size"])
+    for length, support, before, after in g["pad_cases"]:
+        assert rlgc_ref.axis_linear_fft_padding(int(length), int(support)) == (before, after)
+    # config-2 headline shape: 64x2048x2048 with a 64x51x51 PSF -> 128x2187x2187
+    assert [s + sum(rlgc_ref.axis_linear_fft_padding(s, p)) for s, p in
+            zip((64, 2048, 2048), (64, 51, 51))] == [128, 2187, 2187]
+
+
+def test_symmetric_boundary_composes_to_one_gather():
+    rng = np.random.default_rng(0)
+    pad = ((3, 4), (5, 2), (1, 7))  # includes pads larger than the observed extent
+    core = (2, 4, 3)
+    shape = tuple(c + b + a for c, (b, a) in zip(core, pad))
+    vol = rng.normal(size=shape).astype(np.float32)
+    ref = vol.copy()
+    rlgc_ref.enforce_symmetric_boundary(ref, pad)
+    idx = [rlgc_ref.symmetric_source_index(n, b, a) for n, (b, a) in zip(shape, pad)]
+    gathered = vol[np.ix_(*idx)]
+    assert np.array_equal(ref, gathered)
+
+
+@pytest.mark.parametrize("name,is3d", [("decode_pixels_16", True), ("decode_pixels_22", True),
+                                       ("decode_pixels_2d_none", False)])
+def test_decode_pixels_matches_reference(golden, name, is3d):
+    g = golden(name)
+    assert np.array_equal(decode_ref.lowpass(g["stack"], (3.0, 1.0, 1.0), is3d), g["lowpass"])
+    kw = dict(magnitude_threshold=(0.7, 10.0))
+    if "background" in g.files:
+        kw = dict(background=g["background"], normalization=g["normalization"],
+                  excluded_indices=g["excluded_indices"],
+                  magnitude_threshold=tuple(g["magnitude_threshold"]))
+    dec, mag, dist, sc = decode_ref.decode_pixels(
+        g["lowpass"], g["decoding_matrix"], float(g["pixel_threshold"]), arith="standin", **kw)
+    assert np.array_equal(dec, g["decoded"])
+    assert np.array_equal(mag, g["magnitude"])
+    assert np.array_equal(dist, g["distance"])
+    assert np.array_equal(sc, g["scaled"])
+    # the device arithmetic (fmaf chain + CuPy's double rounding) changes no integer call
+    dec2, mag2, dist2, sc2 = decode_ref.decode_pixels(
+        g["lowpass"], g["decoding_matrix"], float(g["pixel_threshold"]), arith="device", **kw)
+    assert np.array_equal(dec2, g["decoded"])
+    for a, b in ((mag2, g["magnitude"]), (dist2, g["distance"]), (sc2, g["scaled"])):
+        a32, b32 = a.astype(np.float32), b.astype(np.float32)
+        assert np.max(np.abs(a32 - b32)) <= 1e-3  # at most one float16 ulp apart
+        assert np.mean(a != b) < 1e-3
+
+
+def test_codebook_thresholds_and_normalisation(golden):
+    g = golden("decode_pixels_22")
+    matrix, genes, pix, tr, blank = decode_ref.load_codebook(g["codebook_bits"], list(g["gene_ids"]))
+    assert pix == float(g["pixel_threshold"]) and tr == float(g["transcript_threshold"])
+    assert abs(pix - 0.765367) < 1e-6 and abs(tr - 0.605811) < 1e-6
+    assert blank == int(g["blank_count"])
+    assert np.array_equal(decode_ref.normalize_codebook(matrix), g["decoding_matrix"])
+
+
+def test_warp_pixel_known_answer(golden):
+    g = golden("warp_pixel")
+    got = decode_ref.warp_pixel(g["pixel"], g["spacing"], g["origin"], g["affine"], g["camera_to_stage"])
+    np.testing.assert_allclose(got, g["expected"], rtol=0, atol=1e-5)
+    got = decode_ref.warp_pixel(g["pixel"], g["spacing"], g["origin"], g["affine"], None)
+    np.testing.assert_allclose(got, g["expected_no_camera"], rtol=0, atol=1e-5)
+
+
+def test_philox_known_answer_and_binomial_moments():
+    # Random123 known-answer vectors for philox4x32-10
+    out = philox.philox4x32_10([0], [0], [0], [0], 0, 0)
+    assert [int(o[0]) for o in out] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    out = philox.philox4x32_10([0xFFFFFFFF], [0xFFFFFFFF], [0xFFFFFFFF], [0xFFFFFFFF],
+                               0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(o[0]) for o in out] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    n = np.full(200000, 300, dtype=np.int64)
+    s = philox.binomial_half(n, np.arange(n.size), 3, 42)
+    assert abs(s.mean() - 150.0) < 0.1 and abs(s.var() - 75.0) < 1.0
+    assert s.min() >= 0 and s.max() <= 300
+    edge = philox.binomial_half(np.array([0, 1, 127, 128, 129, 65535]), np.arange(6), 0, 1)
+    assert edge[0] == 0 and edge[1] in (0, 1) and 20000 < edge[5] < 45000
