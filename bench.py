@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mvoxels/s through decon + decode on synthetic MERFISH tiles.
+
+One *step* = the per-tile hot path on one synthetic tile held in HBM:
+B x RLGC deconvolution of the readout images (one per bit, clip -> uint16 like
+DataRegistration.py:993-995) followed by one full ``PixelDecoder.decode_one_tile``
+(readout x predictor, low-pass, fused pixel decode, connected components, transcript
+table).  Default workload = BASELINE.json ``configs[1]``: 64 x 2048 x 2048 tile, 22-bit /
+140-codeword codebook, PSF 64 x 51 x 51 (FFT volume 128 x 2187 x 2187).
+
+    python bench.py --gpus 1 --steps 1 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Tiles are independent: every rank decodes its own tile per step (weak scaling, no
+data-path collective; RCCL is only used for the timing barrier / max-reduce here).
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import importlib
+import itertools
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+import torch
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (tile zyx, bits, psf zyx, emitters)
+    "config2": ((64, 2048, 2048), 22, (64, 51, 51), 80_000),
+    "config1": ((16, 256, 256), 16, (16, 51, 51), 1_200),
+}
+RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL = 20.0  # 2 FFTs x 8 B + OTF read 4 B
+HBM_PEAK_GBS = 8000.0
+
+
+def hw4_codebook(n_bits: int, n_codes: int = 140, n_blank: int = 10, seed: int = 0) -> pd.DataFrame:
+    """Greedy weight-4 / Hamming-distance-4 codebook (MHD4 family used by the reference data)."""
+    rng = np.random.default_rng(seed)
+    combos = list(itertools.combinations(range(n_bits), 4))
+    rng.shuffle(combos)
+    chosen: list[tuple] = []
+    for c in combos:
+        s = set(c)
+        if all(len(s & set(o)) <= 2 for o in chosen):
+            chosen.append(c)
+        if len(chosen) == n_codes:
+            break
+    bits = np.zeros((len(chosen), n_bits), dtype=np.int64)
+    for i, c in enumerate(chosen):
+        bits[i, list(c)] = 1
+    names = [f"gene{i:03d}" for i in range(len(chosen) - n_blank)] + [f"Blank-{i:02d}" for i in range(n_blank)]
+    df = pd.DataFrame(bits, columns=[f"bit{i + 1:02d}" for i in range(n_bits)])
+    df.insert(0, "gene_id", names)
+    return df
+
+
+def gaussian_psf(shape, sigma, device):
+    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=device, dtype=torch.float64) - n // 2 for n in shape],
+                                indexing="ij")
+    psf = torch.exp(-0.5 * ((zz / sigma[0]) ** 2 + (yy / sigma[1]) ** 2 + (xx / sigma[2]) ** 2))
+    return (psf / psf.sum()).to(torch.float32).contiguous()
+
+
+def make_tile(shape, bits_matrix, n_emitters, seed, device, kernels):
+    """uint16 readouts + float32 predictor images of one synthetic tile, generated in HBM."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    C, B = bits_matrix.shape
+    z = torch.randint(2, shape[0] - 2, (n_emitters,), device=device, generator=gen)
+    y = torch.randint(4, shape[1] - 4, (n_emitters,), device=device, generator=gen)
+    x = torch.randint(4, shape[2] - 4, (n_emitters,), device=device, generator=gen)
+    code = torch.randint(0, C, (n_emitters,), device=device, generator=gen)
+    amp = (torch.rand(n_emitters, device=device, generator=gen) * 600 + 300) / 0.0138  # 300-900 peak photons
+    on = torch.from_numpy(bits_matrix).to(device)[code]  # [E, B]
+    readouts, predictors = [], []
+    scratch = torch.empty(shape, dtype=torch.float32, device=device)
+    for b in range(B):
+        sel = on[:, b] > 0
+        vol = torch.zeros(shape, dtype=torch.float32, device=device)
+        jitter = torch.rand(int(sel.sum()), device=device, generator=gen) * 0.4 + 0.8
+        vol.index_put_((z[sel], y[sel], x[sel]), amp[sel] * jitter, accumulate=True)
+        kernels.gaussian_lowpass(vol, (1.8, 1.6, 1.6), True, out=vol, scratch=scratch)  # PSF blur
+        vol += 100.0
+        img = torch.poisson(vol, generator=gen).clamp_(0, 65535).to(torch.uint16)
+        readouts.append(img)
+        pred = torch.zeros(shape, dtype=torch.float32, device=device)
+        pred.index_put_((z[sel], y[sel], x[sel]), torch.ones(int(sel.sum()), device=device), accumulate=True)
+        kernels.gaussian_lowpass(pred, (1.0, 1.2, 1.2), True, out=pred, scratch=scratch)
+        pred.mul_(1.0 / 0.0441)  # blob peak -> 1
+        pred += torch.rand(shape, device=device, generator=gen) * 0.02  # predictor floor (never exactly 0)
+        pred.clamp_(0.0, 1.0)
+        predictors.append(pred)
+        del vol
+    truth = torch.stack([code, z, y, x], dim=1).cpu().numpy()
+    return readouts, predictors, truth
+
+
+def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
+    """Oracle (NumPy/SciPy/C restatement) timed on a bounded crop of the same workload."""
+    from oracle import ccl_ref, decode_ref, rlgc_ref
+
+    cz, cy, cx = min(tile_shape[0], 64), min(tile_shape[1], 160), min(tile_shape[2], 160)
+    crop = readout0[:cz, :cy, :cx].cpu().numpy()
+    psf_np = psf.cpu().numpy()
+    t0 = time.perf_counter()
+    _out, info = rlgc_ref.rlgc(crop, psf_np, rng="philox", max_iterations=2, return_info=True)
+    t_rl = time.perf_counter() - t0
+    np_crop = float(np.prod(info.padded_shape))
+    # 2 iterations + setup (~1 iteration's worth of FFTs): cost per padded voxel-iteration
+    per_vox_iter = t_rl / (3.0 * np_crop)
+    rl = importlib.import_module("merfish3d-analysis_amd.utils.rlgc")
+    pads = rl.pad_widths_zyx(tile_shape, psf_np.shape)
+    np_full = float(np.prod([s + a + b for s, (a, b) in zip(tile_shape, pads)]))
+    # decode sample: 4 planes x crop, all bits
+    rng = np.random.default_rng(0)
+    sample = rng.gamma(2.0, 50.0, size=(n_bits, 4, cy, cx)).astype(np.float32)
+    cb = decode_ref.normalize_codebook(bits_matrix)
+    t0 = time.perf_counter()
+    lp = decode_ref.lowpass(sample, (3.0, 1.0, 1.0), True)
+    dec, mag, dist, sc = decode_ref.decode_pixels(lp, cb, 0.7653669, (0.5, 10.0),
+                                                  background=np.full(n_bits, 20, np.float32),
+                                                  normalization=np.full(n_bits, 200, np.float32))
+    ccl_ref.extract_barcodes(dec, sc, mag, dist, bits_matrix, [f"g{i}" for i in range(len(bits_matrix))],
+                             0.6058, minimum_pixels=3)
+    t_dec = time.perf_counter() - t0
+    n_tile = float(np.prod(tile_shape))
+    tile_seconds = n_bits * max(iters_per_bit, 1.0) * per_vox_iter * np_full + t_dec * n_tile / float(4 * cy * cx)
+    return {
+        "value": n_tile / tile_seconds / 1e6,
+        "unit": "Mvoxels/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": (f"oracle RLGC 2 iterations on a {cz}x{cy}x{cx} crop (FFT volume "
+                   f"{'x'.join(str(v) for v in info.padded_shape)}, {t_rl:.1f}s) + oracle low-pass/decode/extract on "
+                   f"4x{cy}x{cx}x{n_bits} bits ({t_dec:.1f}s), extrapolated linearly to {n_bits} bits x "
+                   f"{iters_per_bit:.1f} iterations on the full tile"),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__  # noqa: F401  (puts the repo root on sys.path)
+
+    kernels = importlib.import_module("merfish3d-analysis_amd.kernels")
+    rl = importlib.import_module("merfish3d-analysis_amd.utils.rlgc")
+    PD = importlib.import_module("merfish3d-analysis_amd.PixelDecoder")
+    DS = importlib.import_module("merfish3d-analysis_amd.datastore")
+
+    shape, n_bits, psf_shape, n_emitters = WORKLOADS[args.workload]
+    codebook = hw4_codebook(n_bits)
+    bits_matrix = codebook.iloc[:, 1:].to_numpy(dtype=np.int64)
+    psf = gaussian_psf(psf_shape, (1.8, 1.6, 1.6), device)
+    readouts, predictors, _truth = make_tile(shape, bits_matrix, n_emitters, 1 + rank, device, kernels)
+
+    store = DS.InMemoryDataStore(num_tiles=1, num_rounds=1, num_bits=n_bits, codebook=codebook)
+    for b in range(n_bits):
+        store.set_corrected_image(readouts[b], tile=0, bit=b)
+        store.save_local_feature_predictor_image(predictors[b], tile=0, bit=b)
+    decoder = PD.PixelDecoder(store, merfish_bits=n_bits, verbose=0)
+    decon = torch.empty(shape, dtype=torch.float32, device=device)
+    stats = {"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0}
+
+    def deconvolve_bits(profile: bool) -> None:
+        for b in range(n_bits):  # DataRegistration._apply_bits_on_gpu: decon -> clip -> uint16
+            _o, info = rl.rlgc_device(readouts[b], psf, rng_seed=42, out=decon, profile=profile)
+            stats["iters"] += info.iterations
+            stats["conv_ms"] += info.conv_ms_total
+            stats["conv_calls"] += info.conv_calls
+            store.save_local_deconvolved_readout_image(kernels.clip_to_u16(decon), tile=0, bit=b)
+
+    def step(profile: bool) -> None:
+        deconvolve_bits(profile)
+        decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
+        stats["transcripts"] = len(decoder.decoded_barcodes)
+
+    def fix_normalization() -> None:
+        """Per-dataset analysis parameters, set once before timing: background = median and
+        normalisation = 99.9th percentile (minus background) of each bit's low-passed
+        readout x predictor product (exact radix select on the device)."""
+        decoder._tile_idx = 0
+        decoder._load_bit_data(gpu_id=local_rank)
+        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=local_rank)
+        bkd = np.zeros(n_bits, dtype=np.float32)
+        nrm = np.ones(n_bits, dtype=np.float32)
+        for b in range(n_bits):
+            pool = kernels.PooledValues(group=False)
+            pool.add(decoder._image_data_lp[b])
+            bkd[b] = pool.percentile(50.0)
+            nrm[b] = max(pool.percentile(99.9) - bkd[b], 1e-3)
+        store.save_decode_normalization_vectors(None, "global", nrm, bkd)
+        decoder._cleanup()
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # untimed: first pass deconvolves so the per-dataset global normalisation vectors exist
+    for w in range(max(args.warmup, 1)):
+        if w == 0:
+            deconvolve_bits(False)
+            fix_normalization()
+            decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
+        else:
+            step(False)
+    for k in stats:
+        stats[k] = 0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        it = torch.tensor([stats["iters"]], dtype=torch.float64, device=device)
+        dist.all_reduce(it, op=dist.ReduceOp.SUM)
+        total_iters = float(it.item())
+    else:
+        total_iters = float(stats["iters"])
+
+    if rank == 0:
+        n_tile = float(np.prod(shape))
+        value = world * args.steps * n_tile / elapsed / 1e6
+        pads = rl.pad_widths_zyx(shape, psf_shape)
+        padded = [s + a + b for s, (a, b) in zip(shape, pads)]
+        np_full = float(np.prod(padded))
+        conv_ms = stats["conv_ms"] / max(stats["conv_calls"], 1)
+        achieved = RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full / (conv_ms * 1e-3) / 1e9 if conv_ms else 0.0
+        out = {
+            "metric": "Mvoxels/s through decon+decode, 22-bit codebook, 2048^2x64 tile",
+            "value": round(value, 4),
+            "unit": "Mvoxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"configs[{1 if args.workload == 'config2' else 0}]: synthetic "
+                             f"{shape[0]}x{shape[1]}x{shape[2]} tile per GPU, {n_bits}-bit/{len(bits_matrix)}-codeword "
+                             f"codebook, {n_bits} x RLGC (PSF {'x'.join(map(str, psf_shape))}, FFT volume "
+                             f"{'x'.join(map(str, padded))}) + decode_one_tile"),
+                "tiles_per_step": world,
+                "emitters_per_tile": n_emitters,
+            },
+            "rlgc_iterations_total": total_iters,
+            "mvoxel_iterations_per_s": round(total_iters * n_tile / elapsed / 1e6, 2),
+            "transcripts_rank0": stats["transcripts"],
+            "roofline": {
+                "kernel": "fft_conv (rocFFT r2c + k_cmul + rocFFT c2r), 4 per RLGC iteration",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "avg_ms": round(conv_ms, 3),
+                "launches": stats["conv_calls"],
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            iters_per_bit = total_iters / max(args.steps * n_bits, 1)
+            out["cpu_baseline"] = cpu_baseline(readouts[0], psf, bits_matrix, shape, n_bits, iters_per_bit)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

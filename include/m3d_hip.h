@@ -63,6 +63,8 @@ typedef struct m3d_rlgc_params {
     uint64_t seed;          /* rlgc.py:564: split seed (42; +tile_idx when tiled, :983)     */
     int32_t normalize_psf;  /* rlgc.py:310-312                                              */
     int32_t max_iterations; /* 0 = unbounded like the reference; >0 is a test/bench bound   */
+    int32_t profile;        /* != 0: HIP-event timing of every FFT convolution (bench.py)   */
+    int32_t reserved;
 } m3d_rlgc_params;
 
 #define M3D_RLGC_TRACE_CAP 512
@@ -78,6 +80,9 @@ typedef struct m3d_rlgc_result {
     double max_relative_delta[M3D_RLGC_TRACE_CAP]; /* rlgc.py:692 */
     double update_min[M3D_RLGC_TRACE_CAP];         /* rlgc.py:690 */
     double update_max[M3D_RLGC_TRACE_CAP];         /* rlgc.py:691 */
+    double conv_ms_total; /* profile: summed device time of the fft_conv calls (rlgc.py:316-350) */
+    int32_t conv_calls;   /* profile: number of fft_conv calls timed                          */
+    int32_t reserved2;
 } m3d_rlgc_result;
 
 /* Creates rocFFT plans for the padded shape (replaces the cuFFT plan cache +
@@ -128,13 +133,87 @@ int m3d_gaussian_lowpass(const float *in, float *out, float *scratch, const int3
  *  codebook    f32 [C, B] unit-norm codewords
  *  excluded    int32[n_excluded] codeword indices (may be NULL)
  * outputs: decoded int16[N]; magnitude, distance f16[N]; scaled f16[B, N];
- *          optional f32 magnitude/distance before quantisation (may be NULL). */
+ *          optional f32 magnitude/distance before quantisation (may be NULL).
+ * flags: M3D_DECODE_PRENORMALIZED - rows of `stack` are already unit-norm traces; only the
+ *        distance / argmin / call runs (_calculate_distances, PixelDecoder.py:2470-2521). */
+#define M3D_DECODE_PRENORMALIZED 1
 int m3d_decode_pixels(const float *stack, int32_t B, int64_t N, const float *background,
                       const float *normalization, const float *codebook, int32_t C,
                       float pixel_threshold, float magnitude_lo, float magnitude_hi,
                       const int32_t *excluded, int32_t n_excluded, int16_t *decoded,
                       uint16_t *magnitude_f16, uint16_t *distance_f16, uint16_t *scaled_f16,
-                      float *magnitude_f32, float *distance_f32, void *stream);
+                      float *magnitude_f32, float *distance_f32, int32_t flags, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Transcript extraction  (PixelDecoder._extract_barcodes, PixelDecoder.py:2908-3201)
+ * ---------------------------------------------------------------------------------- */
+
+/* cucim.skimage.measure.label(decoded, background=-1, connectivity=c), PixelDecoder.py:2946-2972.
+ * Components are regions of EQUAL codeword id.  per_plane != 0 labels every z plane on its
+ * own (the 2-D decode mode).  Outputs:
+ *   labels int32[N]: voxel index of the component's raster-first voxel (its root), -1 = background
+ *   slot   int32[N]: at root voxels, a dense component number in [0, *n_components)
+ *   n_components: device int32 scalar */
+int m3d_ccl_label(const int16_t *decoded, const int32_t shape_zyx[3], int connectivity,
+                  int per_plane, int32_t *labels, int32_t *slot, int32_t *n_components,
+                  void *stream);
+
+/* regionprops_table columns used at PixelDecoder.py:2991-3042 as exact per-component sums.
+ *   intensity: f16 or f32 [B, N] (scaled traces, or raw low-passed data while optimising
+ *              normalisation, :2935-2941); magnitude/distance: f16 [N]
+ * outputs per component slot s:
+ *   comp_root[s]  voxel index of the first voxel (label order = ascending root)
+ *   comp_code[s]  codeword id of the component (label -> codeword map of :3066-3078)
+ *   comp_min_distance[s]  intensity_min of the distance image (:2991-2995)
+ *   comp_sums[s][11 + B] = area, sum z, y, x, sum zz, yy, xx, zy, zx, yx, sum magnitude,
+ *                          sum intensity[0..B)   (doubles; exact for f16 inputs) */
+int m3d_region_stats(const int16_t *decoded, const int32_t *labels, const int32_t *slot,
+                     const int32_t shape_zyx[3], int32_t B, const void *intensity,
+                     int intensity_dtype, const uint16_t *magnitude_f16,
+                     const uint16_t *distance_f16, int32_t n_components, int32_t *comp_root,
+                     int32_t *comp_code, float *comp_min_distance, double *comp_sums, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Global normalisation statistics  (PixelDecoder._global_normalization_vectors, :981-1199)
+ * ---------------------------------------------------------------------------------- */
+
+/* One pass of an exact 8-bit radix select over float32 values: adds to hist256 (device
+ * int64[256], caller zeroes it) the histogram of key byte `pass` (0 = most significant) of
+ * all values whose more significant key bytes equal those of `prefix`.  Optional on-the-fly
+ * transform (1: max(x - sub, 0), PixelDecoder.py:1144-1148) and filter (1: x < thr, :1115;
+ * 2: x > thr, :1162).  Summing the histograms of several GPUs (RCCL all-reduce) gives the
+ * pooled order statistic cp.percentile / cp.median compute at :1113, :1127, :1157, :1177. */
+int m3d_radix_hist(const float *values, int64_t n, int transform, float sub, int filter, double thr,
+                   int pass, uint32_t prefix, int64_t *hist256, void *stream);
+
+/* image[image > threshold] = replacement, PixelDecoder.py:1072-1074 (hot pixels) */
+int m3d_replace_above(float *values, int64_t n, float threshold, float replacement, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Resampling  (utils/multiview_registration.py)
+ * ---------------------------------------------------------------------------------- */
+#define M3D_MODE_CONSTANT 0 /* scipy mode="constant": cval outside [0, n-1]          */
+#define M3D_MODE_NEAREST 1  /* scipy mode="nearest": clamp to the edge sample         */
+
+/* _max_z_projection_gpu, multiview_registration.py:57-77: f32[Y,X] = max over Z */
+int m3d_max_z(const void *in, int dtype, const int32_t shape_zyx[3], float *out, void *stream);
+
+/* warp_array_to_reference_gpu, multiview_registration.py:797-902:
+ * cupyx.scipy.ndimage.affine_transform(order=1) with matrix_px / offset_px as built at
+ * :867-868 (host doubles).  Output dtype = input dtype (u16 | f32). */
+int m3d_affine_warp(const void *in, int dtype, const int32_t in_shape_zyx[3],
+                    const double matrix_px_host[9], const double offset_px_host[3], void *out,
+                    const int32_t out_shape_zyx[3], int mode, double cval, void *stream);
+
+/* warp_array_to_reference_with_affine_and_sofima_flow_gpu, multiview_registration.py:905-1131.
+ *  flow_xyz f32 [3, fz, fy, fx] (channels X,Y,Z); stride / box start / spacing / origin in
+ *  Z,Y,X order; transform = 4x4 physical matrix, row major (host floats). */
+int m3d_flow_warp(const void *in, int dtype, const int32_t in_shape_zyx[3], void *out,
+                  const int32_t out_shape_zyx[3], const float *flow_xyz,
+                  const int32_t flow_shape_zyx[3], const float stride_zyx_host[3],
+                  const float box_start_zyx_host[3], const float spacing_zyx_host[3],
+                  const float origin_zyx_host[3], const float transform_zyx_um_host[16], int mode,
+                  float cval, void *stream);
 
 #ifdef __cplusplus
 }

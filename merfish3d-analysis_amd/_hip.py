@@ -31,6 +31,8 @@ class RLGCParams(ctypes.Structure):
         ("seed", c_uint64),
         ("normalize_psf", c_int32),
         ("max_iterations", c_int32),
+        ("profile", c_int32),
+        ("reserved", c_int32),
     ]
 
 
@@ -47,6 +49,9 @@ class RLGCResult(ctypes.Structure):
         ("max_relative_delta", ctypes.c_double * TRACE_CAP),
         ("update_min", ctypes.c_double * TRACE_CAP),
         ("update_max", ctypes.c_double * TRACE_CAP),
+        ("conv_ms_total", ctypes.c_double),
+        ("conv_calls", c_int32),
+        ("reserved2", c_int32),
     ]
 
 
@@ -77,7 +82,29 @@ _SIGNATURES = {
         c_int,
         [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_float, c_float,
          c_float, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_void_p],
+         c_int32, c_void_p],
+    ),
+    "m3d_ccl_label": (c_int, [c_void_p, _I3, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "m3d_region_stats": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, _I3, c_int32, c_void_p, c_int, c_void_p, c_void_p, c_int32,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "m3d_radix_hist": (
+        c_int,
+        [c_void_p, c_int64, c_int, c_float, c_int, ctypes.c_double, c_int, ctypes.c_uint32, c_void_p, c_void_p],
+    ),
+    "m3d_replace_above": (c_int, [c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "m3d_max_z": (c_int, [c_void_p, c_int, _I3, c_void_p, c_void_p]),
+    "m3d_affine_warp": (
+        c_int,
+        [c_void_p, c_int, _I3, ctypes.c_double * 9, ctypes.c_double * 3, c_void_p, _I3, c_int,
+         ctypes.c_double, c_void_p],
+    ),
+    "m3d_flow_warp": (
+        c_int,
+        [c_void_p, c_int, _I3, c_void_p, _I3, c_void_p, _I3, _F3, _F3, _F3, _F3, c_float * 16,
+         c_int, c_float, c_void_p],
     ),
 }
 

@@ -133,6 +133,19 @@ __device__ __forceinline__ T block_min(T v, T *smem)
     return r;
 }
 
+// ---- IEEE-exact float32 primitives -----------------------------------------------------------
+// hipcc's __fsqrt_rn is the approximate native sqrt unless OCML_BASIC_ROUNDED_OPERATIONS is
+// defined, and __fadd_rn / __fmul_rn are plain operators: with -ffp-contract=off (set in the
+// Makefile) the plain operators are already single-rounded, and `/` and sqrtf() are correctly
+// rounded by default (-fhip-fp32-correctly-rounded-divide-sqrt).  These wrappers document
+// every place where the result must match the CPU oracle bit for bit.
+__device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float rn_div(float a, float b) { return a / b; }
+__device__ __forceinline__ float rn_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float rn_sqrt(float a) { return __builtin_sqrtf(a); }
+
 // ---- float16 (IEEE binary16, round-to-nearest-even) as raw bits ---------------------------
 __device__ __forceinline__ uint16_t f32_to_f16_bits(float f)
 {

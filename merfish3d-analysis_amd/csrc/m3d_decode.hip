@@ -62,7 +62,7 @@ __global__ void k_gauss_walk(const float *__restrict__ in, float *__restrict__ o
             win[2 * R] = in[base + (int64_t)reflect_idx(t + R, len) * stride];
             float acc = 0.0f;
 #pragma unroll
-            for (int k = 0; k <= 2 * R; ++k) acc = __fmaf_rn(gw.w[k], win[k], acc);
+            for (int k = 0; k <= 2 * R; ++k) acc = rn_fma(gw.w[k], win[k], acc);
             out[base + (int64_t)t * stride] = acc;
 #pragma unroll
             for (int k = 0; k < 2 * R; ++k) win[k] = win[k + 1];
@@ -82,7 +82,7 @@ __global__ void k_gauss_direct(const float *__restrict__ in, float *__restrict__
         for (int t = 0; t < len; ++t) {
             float acc = 0.0f;
             for (int k = 0; k <= 2 * R; ++k)
-                acc = __fmaf_rn(gw.w[k], in[base + (int64_t)reflect_idx(t + k - R, len) * stride], acc);
+                acc = rn_fma(gw.w[k], in[base + (int64_t)reflect_idx(t + k - R, len) * stride], acc);
             out[base + (int64_t)t * stride] = acc;
         }
     }
@@ -103,7 +103,7 @@ __global__ void k_gauss_x(const float *__restrict__ in, float *__restrict__ out,
         for (int x = threadIdx.x; x < X; x += blockDim.x) {
             float acc = 0.0f;
             for (int k = 0; k <= 2 * R; ++k)
-                acc = __fmaf_rn(gw.w[k], row_lds[reflect_idx(x + k - R, X)], acc);
+                acc = rn_fma(gw.w[k], row_lds[reflect_idx(x + k - R, X)], acc);
             dst[x] = acc;
         }
     }
@@ -174,7 +174,7 @@ struct DecodeArgs {
     float *magnitude_f32;
     float *distance_f32;
     int64_t N;
-    int32_t B, C, n_excluded, NT;
+    int32_t B, C, n_excluded, NT, prenormalized;
     float thr, lo, hi;
 };
 
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
         if (c < a.C)
             for (int b = 0; b < a.B; ++b) {
                 const float v = a.codebook[(size_t)c * a.B + b];
-                acc = __fmaf_rn(v, v, acc);
+                acc = rn_fma(v, v, acc);
             }
         yn[c] = acc;
         int e = 0;
@@ -233,23 +233,25 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
 #pragma unroll
         for (int b = 0; b < 2 * KS; ++b) {
             float v = (valid && b < a.B) ? a.stack[(size_t)b * a.N + p] : 0.0f;
-            if (use_norm) v = __fdiv_rn(__fsub_rn(v, bk[b]), nm[b]);
-            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            if (!a.prenormalized) {
+                if (use_norm) v = rn_div(rn_sub(v, bk[b]), nm[b]);
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+            }
             s[b] = (b < a.B) ? v : 0.0f;
         }
         // ---- L2 norm over bits, sequential like add.reduce(axis=0) (:2459-2462)
-        float acc = __fmul_rn(s[0], s[0]);
+        float acc = rn_mul(s[0], s[0]);
 #pragma unroll
-        for (int b = 1; b < 2 * KS; ++b) acc = __fadd_rn(acc, __fmul_rn(s[b], s[b]));
-        const float nrm = __fsqrt_rn(acc);
+        for (int b = 1; b < 2 * KS; ++b) acc = rn_add(acc, rn_mul(s[b], s[b]));
+        const float nrm = rn_sqrt(acc);
         const float mag = (nrm == 0.0f) ? -1.0f : nrm;
         const float den = (nrm == 0.0f) ? INFINITY : nrm;
         float xn[2 * KS];
         float XN = 0.0f;
 #pragma unroll
         for (int b = 0; b < 2 * KS; ++b) {
-            xn[b] = __fdiv_rn(s[b], den);
-            XN = __fmaf_rn(xn[b], xn[b], XN);
+            xn[b] = a.prenormalized ? s[b] : rn_div(s[b], den);
+            XN = rn_fma(xn[b], xn[b], XN);
         }
 
         float my_d = INFINITY;
@@ -278,12 +280,12 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float tt = __fadd_rn(xn_t, yn[c]);
-                    const float d2 = fmaxf(__fsub_rn(tt, __fmul_rn(2.0f, d[r])), 0.0f);
+                    const float tt = rn_add(xn_t, yn[c]);
+                    const float d2 = fmaxf(rn_sub(tt, rn_mul(2.0f, d[r])), 0.0f);
                     if (c < a.C && d2 < best2) {
                         // d = sqrt_rn(d2) is monotone: a smaller d2 wins unless it rounds to
                         // the same distance, where the earlier codeword must be kept
-                        if (d2 >= best2 * 0.9999995f && __fsqrt_rn(d2) == __fsqrt_rn(best2)) {
+                        if (d2 >= best2 * 0.9999995f && rn_sqrt(d2) == rn_sqrt(best2)) {
                             best2 = d2;
                         } else {
                             best2 = d2;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
                 }
             }
             // merge the two half-waves (rows +0 / +4 of every 8)
-            float bd = __fsqrt_rn(best2);
+            float bd = rn_sqrt(best2);
             const float od = __shfl_xor(bd, 32, 64);
             const int oi = __shfl_xor(besti, 32, 64);
             if (od < bd || (od == bd && oi < besti)) {
@@ -378,7 +380,7 @@ int m3d_decode_pixels(const float *stack, int32_t B, int64_t N, const float *bac
                       float pixel_threshold, float magnitude_lo, float magnitude_hi,
                       const int32_t *excluded, int32_t n_excluded, int16_t *decoded,
                       uint16_t *magnitude_f16, uint16_t *distance_f16, uint16_t *scaled_f16,
-                      float *magnitude_f32, float *distance_f32, void *stream)
+                      float *magnitude_f32, float *distance_f32, int32_t flags, void *stream)
 {
     M3D_REQUIRE(stack && codebook && decoded && magnitude_f16 && distance_f16 && scaled_f16,
                 "null pointer");
@@ -415,6 +417,7 @@ int m3d_decode_pixels(const float *stack, int32_t B, int64_t N, const float *bac
     a.C = C;
     a.n_excluded = n_excluded;
     a.NT = NT;
+    a.prenormalized = (flags & M3D_DECODE_PRENORMALIZED) ? 1 : 0;
     a.thr = pixel_threshold;
     a.lo = magnitude_lo;
     a.hi = magnitude_hi;

@@ -31,6 +31,7 @@
 
 #include <cmath>
 #include <new>
+#include <vector>
 
 #include "m3d_common.h"
 #include "m3d_index.h"
@@ -243,8 +244,8 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
             }
             // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668
             const float den = 0.5f * (h + 1e-12f);
-            r1[prow + x] = __fdiv_rn(s1, den);
-            r2[prow + x] = __fdiv_rn(s2, den);
+            r1[prow + x] = rn_div(s1, den);
+            r2[prow + x] = rn_div(s2, den);
         }
     }
     // flatten (64,4) block for the reductions
@@ -304,8 +305,8 @@ __global__ void k_consensus_in(float *__restrict__ w1, const float *__restrict__
         const int64_t base = r * g.Xp;
         for (int x = threadIdx.x; x < g.Xp; x += 64) {
             const float u = un[base + x];
-            const float h1 = __fdiv_rn(w1[base + x], u);
-            const float h2 = __fdiv_rn(w2[base + x], u);
+            const float h1 = rn_div(w1[base + x], u);
+            const float h2 = rn_div(w2[base + x], u);
             prod[base + x] = (h1 - 1.0f) * (h2 - 1.0f);
             const float hs = h1 + h2;
             mn = fminf(mn, hs);
@@ -455,6 +456,7 @@ struct m3d_rlgc_plan {
     size_t o_otf, o_cbuf, o_un, o_ra, o_rb, o_hu, o_r1, o_r2, o_w1, o_w2, o_part, o_status,
         o_fftwork;
     Status *status_host = nullptr;  // pinned
+    std::vector<hipEvent_t> events;  // reused across runs when params->profile is set
 };
 
 #define M3D_ROCFFT_CHECK(expr)                                   \
@@ -622,6 +624,7 @@ int m3d_rlgc_plan_destroy(m3d_rlgc_plan *p)
     if (p->fwd) rocfft_plan_destroy(p->fwd);
     if (p->inv) rocfft_plan_destroy(p->inv);
     if (p->status_host) (void)hipHostFree(p->status_host);
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     delete p;
     return M3D_OK;
 }
@@ -679,13 +682,28 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         return M3D_OK;
     };
     // fft_conv (rlgc.py:316-350) with H in {otf, conj(otf), |otf|^2}
+    // optional HIP-event timing of every convolution (bench.py roofline; params->profile)
+    std::vector<hipEvent_t> &ev = p->events;
+    size_t ev_used = 0;
+    auto stamp = [&]() -> int {
+        if (!params->profile) return M3D_OK;
+        if (ev_used == ev.size()) {
+            hipEvent_t e;
+            M3D_HIP_CHECK(hipEventCreate(&e));
+            ev.push_back(e);
+        }
+        M3D_HIP_CHECK(hipEventRecord(ev[ev_used++], st));
+        return M3D_OK;
+    };
     auto conv = [&](float *src, int mode, float *dst) -> int {
-        int rc = fft_r2c(src, cbuf);
+        int rc = stamp();
         if (rc) return rc;
+        if ((rc = fft_r2c(src, cbuf))) return rc;
         hipLaunchKernelGGL(k_cmul, dim3(grid_for(g.Nc)), dim3(kBlock), 0, st, cbuf, otf, g.Nc,
                            mode, inv_n);
         M3D_KERNEL_CHECK();
-        return fft_c2r(cbuf, dst);
+        if ((rc = fft_c2r(cbuf, dst))) return rc;
+        return stamp();
     };
     int rc;
 
@@ -829,6 +847,13 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     if (res) {
         res->iterations = num_iters;
         res->stop_reason = stop;
+        res->conv_calls = (int32_t)(ev_used / 2);
+        double total = 0.0;
+        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
+        }
+        res->conv_ms_total = total;
     }
     return M3D_OK;
 }

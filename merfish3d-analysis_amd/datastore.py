@@ -1,0 +1,223 @@
+"""In-memory stand-in for the qi2labDataStore duck-type the tile operators talk to.
+
+The reference's on-disk store (``qi2labDataStore.py``, OME-NGFF zarr3 + JSON + parquet) is
+the drop-in *boundary* and is not re-implemented: the
+operators in this package accept any object with the same properties / ``load_*`` /
+``save_*`` methods.  This class provides exactly those methods on top of dictionaries so the
+operators can be exercised (tests, ``bench.py``) without zarr/tensorstore - the same role
+the ``SimpleNamespace`` / dataclass fakes play in the reference's own tests
+(``tests/test_chromatic_estimator.py:9-27``).  Arrays may be NumPy arrays or torch tensors
+already in HBM (then nothing crosses PCIe when an operator loads them).
+"""
+
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+import pandas as pd
+
+
+class _Ready:
+    """Mimics the tensorstore future returned with ``return_future=True`` (:2264-2267)."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
+class InMemoryDataStore:
+    def __init__(self, *, num_tiles: int, num_rounds: int, num_bits: int, codebook: pd.DataFrame,
+                 voxel_size_zyx_um=(0.315, 0.098, 0.098), microscope_type: str = "3D",
+                 datastore_path: str | Path = "/tmp/m3d_inmemory_datastore"):
+        self.tile_ids = [f"tile{i:04d}" for i in range(num_tiles)]
+        self.round_ids = [f"round{i + 1:03d}" for i in range(num_rounds)]
+        self.bit_ids = [f"bit{i + 1:03d}" for i in range(num_bits)]
+        self.codebook = codebook
+        self.voxel_size_zyx_um = tuple(float(v) for v in voxel_size_zyx_um)
+        self.microscope_type = microscope_type
+        self.channel_psfs = None
+        self.datastore_state = {}
+        self._datastore_path = Path(datastore_path)
+        self._segmentation_root_path = None
+        self.feature_predictor_folder_name = "ufish"
+        self._corrected = {}      # (tile, "round"/"bit", id) -> array
+        self._fiducial_decon = {}
+        self._readout_decon = {}
+        self._predictor = {}
+        self._round_linker = {}   # (tile, bit) -> 1-based round
+        self._wavelengths = {}    # (tile, kind, id) -> (ex, em)
+        self._round_xform = {}
+        self._flow = {}
+        self._stage = {}
+        self._global_xform = {}
+        self._chromatic = {}
+        self._norm_vectors = {}
+        self._norm_meta = {}
+        self._decoded = {}
+        self._filtered = {}
+        self._predictor_spots = {}
+
+    # ---- id helpers (qi2labDataStore.py:2501-2515) ------------------------------------
+    @property
+    def num_tiles(self):
+        return len(self.tile_ids)
+
+    @property
+    def num_bits(self):
+        return len(self.bit_ids)
+
+    def _tile(self, tile):
+        if isinstance(tile, (int, np.integer)):
+            return self.tile_ids[int(tile)] if 0 <= int(tile) < len(self.tile_ids) else None
+        return tile if tile in self.tile_ids else None
+
+    def _round(self, rnd):
+        if isinstance(rnd, (int, np.integer)):
+            return self.round_ids[int(rnd)] if 0 <= int(rnd) < len(self.round_ids) else None
+        return rnd if rnd in self.round_ids else None
+
+    def _bit(self, bit):
+        if isinstance(bit, (int, np.integer)):
+            return self.bit_ids[int(bit)] if 0 <= int(bit) < len(self.bit_ids) else None
+        return bit if bit in self.bit_ids else None
+
+    @staticmethod
+    def _out(value, return_future):
+        return _Ready(value) if return_future else value
+
+    def _key(self, tile, round=None, bit=None):
+        t = self._tile(tile)
+        if t is None or (round is None) == (bit is None):
+            print("Provide a valid tile and either 'round' or 'bit'")  # store convention: print + None
+            return None
+        if round is not None:
+            r = self._round(round)
+            return None if r is None else (t, "round", r)
+        b = self._bit(bit)
+        return None if b is None else (t, "bit", b)
+
+    # ---- images -------------------------------------------------------------------------
+    def set_corrected_image(self, image, tile, round=None, bit=None, wavelengths_um=(0.561, 0.590)):
+        k = self._key(tile, round, bit)
+        self._corrected[k] = image
+        self._wavelengths[k] = tuple(float(v) for v in wavelengths_um)
+
+    def load_local_corrected_image(self, tile, round=None, bit=None, return_future=True):
+        k = self._key(tile, round, bit)
+        if k is None or k not in self._corrected:
+            return None
+        return self._out(self._corrected[k], return_future)
+
+    def _image_shape(self, tile, round=None, bit=None, kind="corrected_data"):
+        k = self._key(tile, round, bit)
+        src = {"corrected_data": self._corrected, "registered_decon_data": self._readout_decon
+               if k and k[1] == "bit" else self._fiducial_decon}.get(kind, self._corrected)
+        arr = src.get(k)
+        return None if arr is None else tuple(int(v) for v in arr.shape)
+
+    def save_local_deconvolved_fiducial_image(self, image, tile, round, **_):
+        self._fiducial_decon[self._key(tile, round=round)] = image
+
+    def load_local_fiducial_image(self, tile, round, return_future=True):
+        k = self._key(tile, round=round)
+        arr = self._fiducial_decon.get(k, self._corrected.get(k))
+        return None if arr is None else self._out(arr, return_future)
+
+    def save_local_deconvolved_readout_image(self, image, tile, bit, **_):
+        self._readout_decon[self._key(tile, bit=bit)] = image
+
+    def load_local_readout_image(self, tile, bit, return_future=True):
+        """Deconvolved readout if present else corrected (qi2labDataStore.py:4709)."""
+        k = self._key(tile, bit=bit)
+        arr = self._readout_decon.get(k, self._corrected.get(k))
+        return None if arr is None else self._out(arr, return_future)
+
+    def save_local_feature_predictor_image(self, image, tile, bit, **_):
+        self._predictor[self._key(tile, bit=bit)] = image
+
+    def load_local_feature_predictor_image(self, tile, bit, return_future=True):
+        arr = self._predictor.get(self._key(tile, bit=bit))
+        return None if arr is None else self._out(arr, return_future)
+
+    def save_local_feature_predictor_spots(self, spots, tile, bit, **_):
+        self._predictor_spots[self._key(tile, bit=bit)] = spots
+
+    # ---- metadata -----------------------------------------------------------------------
+    def set_round_linker(self, tile, bit, round_1based: int):
+        self._round_linker[(self._tile(tile), self._bit(bit))] = int(round_1based)
+
+    def load_local_round_linker(self, tile, bit):
+        return self._round_linker.get((self._tile(tile), self._bit(bit)), 1)
+
+    def load_local_wavelengths_um(self, tile, round=None, bit=None):
+        return self._wavelengths.get(self._key(tile, round, bit), (0.561, 0.590))
+
+    def save_local_round_transform_zyx_um(self, transform, tile, round):
+        self._round_xform[(self._tile(tile), self._round(round))] = np.asarray(transform, dtype=np.float32)
+
+    def load_local_round_transform_zyx_um(self, tile, round):
+        return self._round_xform.get((self._tile(tile), self._round(round)))
+
+    def save_local_sofima_flow_field(self, flow, tile, round, **attrs):
+        self._flow[(self._tile(tile), self._round(round))] = (np.asarray(flow, dtype=np.float32), dict(attrs))
+
+    def load_local_sofima_flow_field(self, tile, round, return_future=False):
+        return self._flow.get((self._tile(tile), self._round(round)))
+
+    def set_chromatic_affine_transform_zyx_um(self, wavelength_um, transform):
+        self._chromatic[round(float(wavelength_um), 4)] = np.asarray(transform, dtype=np.float32)
+
+    def load_chromatic_affine_transform_zyx_um(self, wavelength_um):
+        """Identity fallback like qi2labDataStore.py:213."""
+        return self._chromatic.get(round(float(wavelength_um), 4), np.eye(4, dtype=np.float32))
+
+    def set_stage_position_zyx_um(self, tile, origin, camera_to_stage=None, round=0):
+        c2s = np.eye(4, dtype=np.float32) if camera_to_stage is None else np.asarray(camera_to_stage)
+        self._stage[(self._tile(tile), int(round))] = (np.asarray(origin, dtype=np.float32), c2s)
+
+    def load_local_stage_position_zyx_um(self, tile, round=0):
+        r = round if isinstance(round, (int, np.integer)) else self.round_ids.index(round)
+        return self._stage.get((self._tile(tile), int(r)))
+
+    def set_global_coord_xforms_um(self, tile, affine, origin, spacing):
+        self._global_xform[self._tile(tile)] = (np.asarray(affine), np.asarray(origin), np.asarray(spacing))
+
+    def load_global_coord_xforms_um(self, tile):
+        return self._global_xform.get(self._tile(tile), (None, None, None))
+
+    # ---- decode products -------------------------------------------------------------------
+    def save_decode_normalization_vectors(self, decode_run_key, kind, normalization, background,
+                                          decode_mode=None, metadata=None):
+        self._norm_vectors[(decode_run_key, kind)] = (np.asarray(normalization).copy(),
+                                                      np.asarray(background).copy())
+        self._norm_meta[(decode_run_key, kind)] = dict(metadata or {}, decode_mode=decode_mode)
+
+    def load_decode_normalization_vectors(self, decode_run_key, kind):
+        return self._norm_vectors.get((decode_run_key, kind), (None, None))
+
+    def load_decode_normalization_metadata(self, decode_run_key, kind):
+        return self._norm_meta.get((decode_run_key, kind))
+
+    def decoded_temporary_dir(self, decode_run_key=None):
+        return self._datastore_path / "decoded_temp" / str(decode_run_key or "default")
+
+    def save_local_decoded_spots(self, df, tile, decode_run_key=None):
+        self._decoded[(decode_run_key, self._tile(tile))] = df.copy()
+
+    def load_local_decoded_spots(self, tile, decode_run_key=None):
+        return self._decoded.get((decode_run_key, self._tile(tile)))
+
+    def save_global_filtered_decoded_spots(self, df, decode_run_key=None):
+        self._filtered[decode_run_key] = df.copy()
+
+    def load_global_filtered_decoded_spots(self, decode_run_key=None):
+        return self._filtered.get(decode_run_key)
+
+    def load_global_cellpose_outlines(self):
+        return None
+
+    def load_global_cellpose_roi_zip(self):
+        return None

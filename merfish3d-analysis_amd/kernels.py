@@ -71,7 +71,7 @@ def gaussian_lowpass(volume: torch.Tensor, sigma_zyx, is_3d: bool = True,
 def decode_pixels(stack: torch.Tensor, codebook: torch.Tensor, pixel_threshold: float,
                   magnitude_threshold, background: torch.Tensor | None = None,
                   normalization: torch.Tensor | None = None, excluded_indices=(),
-                  want_f32: bool = False):
+                  want_f32: bool = False, prenormalized: bool = False):
     """Fused ``_decode_pixels`` (PixelDecoder.py:2523-2643).
 
     ``stack`` float32 ``[B,Z,Y,X]``; ``codebook`` ``[C,B]`` unit rows.  Returns
@@ -111,7 +111,8 @@ def decode_pixels(stack: torch.Tensor, codebook: torch.Tensor, pixel_threshold: 
                 stack.data_ptr(), B, N, _hip.ptr(bk), _hip.ptr(nm), cb.data_ptr(), int(cb.shape[0]),
                 thr32, float(magnitude_threshold[0]), float(magnitude_threshold[1]),
                 _hip.ptr(ex), n_ex, decoded.data_ptr(), magnitude.data_ptr(), distance.data_ptr(),
-                scaled.data_ptr(), _hip.ptr(mag32), _hip.ptr(dist32), _stream(stack),
+                scaled.data_ptr(), _hip.ptr(mag32), _hip.ptr(dist32), int(bool(prenormalized)),
+                _stream(stack),
             ),
             "m3d_decode_pixels",
         )
@@ -133,3 +134,228 @@ def rlgc_debug_split(image: torch.Tensor, seed: int, iteration: int) -> torch.Te
                                                    out.data_ptr(), _stream(image)),
                    "m3d_rlgc_debug_split")
     return out
+
+
+SUM_COLS = 11  # area, sz, sy, sx, szz, syy, sxx, szy, szx, syx, magnitude sum (+ B intensity sums)
+
+
+def connected_component_table(decoded: torch.Tensor, intensity: torch.Tensor, magnitude: torch.Tensor,
+                              distance: torch.Tensor, is_3d: bool = True):
+    """CCL + per-component sums (PixelDecoder.py:2946-3042) -> small host arrays.
+
+    ``decoded`` int16 ``[Z,Y,X]``; ``intensity`` float16/float32 ``[B,Z,Y,X]``; ``magnitude``
+    and ``distance`` float16 ``[Z,Y,X]``.  Returns a dict of NumPy arrays with one row per
+    connected component, ordered like scikit-image labels (raster order of first voxel):
+    ``root, code, min_distance, sums[n, 11 + B]``.
+    """
+    dev = decoded.device
+    if decoded.dtype != torch.int16 or decoded.dim() != 3:
+        raise ValueError("decoded must be int16 [Z,Y,X]")
+    decoded = decoded.contiguous()
+    intensity = intensity.contiguous()
+    magnitude = magnitude.contiguous()
+    distance = distance.contiguous()
+    if intensity.dtype not in (torch.float16, torch.float32):
+        raise ValueError("intensity must be float16 or float32")
+    if magnitude.dtype != torch.float16 or distance.dtype != torch.float16:
+        raise ValueError("magnitude and distance must be float16")
+    B = int(intensity.shape[0])
+    shape = tuple(int(v) for v in decoded.shape)
+    labels = torch.empty(shape, dtype=torch.int32, device=dev)
+    slot = torch.empty(shape, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _hip.lib()
+    with torch.cuda.device(dev):
+        _hip.check(lib.m3d_ccl_label(decoded.data_ptr(), _hip.i3(shape), 3 if is_3d else 2,
+                                     0 if is_3d else 1, labels.data_ptr(), slot.data_ptr(),
+                                     count.data_ptr(), _stream(decoded)), "m3d_ccl_label")
+        n = int(count.item())
+        root = torch.empty(n, dtype=torch.int32, device=dev)
+        code = torch.empty(n, dtype=torch.int32, device=dev)
+        mind = torch.empty(n, dtype=torch.float32, device=dev)
+        sums = torch.empty((n, SUM_COLS + B), dtype=torch.float64, device=dev)
+        code_dtype = _hip.M3D_F16 if intensity.dtype == torch.float16 else _hip.M3D_F32
+        _hip.check(lib.m3d_region_stats(decoded.data_ptr(), labels.data_ptr(), slot.data_ptr(),
+                                        _hip.i3(shape), B, intensity.data_ptr(), code_dtype,
+                                        magnitude.data_ptr(), distance.data_ptr(), n,
+                                        _hip.ptr(root) if n else None, _hip.ptr(code) if n else None,
+                                        _hip.ptr(mind) if n else None, _hip.ptr(sums) if n else None,
+                                        _stream(decoded)), "m3d_region_stats")
+    root_h = root.cpu().numpy()
+    order = np.argsort(root_h, kind="stable")
+    return {
+        "root": root_h[order],
+        "code": code.cpu().numpy()[order],
+        "min_distance": mind.cpu().numpy()[order],
+        "sums": sums.cpu().numpy()[order],
+        "labels": labels,
+        "slot": slot,
+    }
+
+
+_MODES = {"constant": 0, "nearest": 1}
+
+
+def _image_dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.uint16:
+        return _hip.M3D_U16
+    if t.dtype == torch.float32:
+        return _hip.M3D_F32
+    raise ValueError(f"volume must be uint16 or float32, got {t.dtype}")
+
+
+def max_z_projection(volume: torch.Tensor) -> torch.Tensor:
+    """``cp.max(image, axis=0)`` as float32 (multiview_registration.py:57-77)."""
+    volume = volume.contiguous()
+    out = torch.empty(tuple(volume.shape[1:]), dtype=torch.float32, device=volume.device)
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_max_z(volume.data_ptr(), _image_dtype_code(volume),
+                                        _hip.i3(volume.shape), out.data_ptr(), _stream(volume)),
+                   "m3d_max_z")
+    return out
+
+
+def affine_warp(volume: torch.Tensor, matrix_px, offset_px, output_shape, mode: str = "constant",
+                cval: float = 0.0) -> torch.Tensor:
+    """``ndimage.affine_transform(order=1)`` with output dtype = input dtype (:883-891)."""
+    import ctypes
+
+    if mode not in _MODES:
+        raise NotImplementedError(f"boundary mode {mode!r} is not supported (constant, nearest)")
+    volume = volume.contiguous()
+    out = torch.empty(tuple(int(v) for v in output_shape), dtype=volume.dtype, device=volume.device)
+    m = (ctypes.c_double * 9)(*[float(v) for v in np.asarray(matrix_px, dtype=np.float64).ravel()])
+    o = (ctypes.c_double * 3)(*[float(v) for v in np.asarray(offset_px, dtype=np.float64).ravel()])
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_affine_warp(volume.data_ptr(), _image_dtype_code(volume),
+                                              _hip.i3(volume.shape), m, o, out.data_ptr(),
+                                              _hip.i3(out.shape), _MODES[mode], float(cval),
+                                              _stream(volume)), "m3d_affine_warp")
+    return out
+
+
+def flow_warp(volume: torch.Tensor, flow_xyz: torch.Tensor, stride_zyx, box_start_zyx, spacing_zyx,
+              origin_zyx, transform_zyx_um, output_shape, mode: str = "constant",
+              cval: float = 0.0) -> torch.Tensor:
+    """Affine + SOFIMA-flow resample in one pass (multiview_registration.py:1027-1101)."""
+    if mode not in _MODES:
+        raise NotImplementedError(f"boundary mode {mode!r} is not supported (constant, nearest)")
+    volume = volume.contiguous()
+    flow_xyz = flow_xyz.to(device=volume.device, dtype=torch.float32).contiguous()
+    if flow_xyz.dim() != 4 or flow_xyz.shape[0] != 3:
+        raise ValueError("SOFIMA flow field must have three XYZ channels.")
+    out = torch.empty(tuple(int(v) for v in output_shape), dtype=volume.dtype, device=volume.device)
+    T = (_hip.c_float * 16)(*[float(v) for v in np.asarray(transform_zyx_um, dtype=np.float32).ravel()])
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_flow_warp(
+            volume.data_ptr(), _image_dtype_code(volume), _hip.i3(volume.shape), out.data_ptr(),
+            _hip.i3(out.shape), flow_xyz.data_ptr(), _hip.i3(flow_xyz.shape[1:]),
+            _hip.f3(np.asarray(stride_zyx, dtype=np.float32)),
+            _hip.f3(np.asarray(box_start_zyx, dtype=np.float32)),
+            _hip.f3(np.asarray(spacing_zyx, dtype=np.float32)),
+            _hip.f3(np.asarray(origin_zyx, dtype=np.float32)), T, _MODES[mode], float(cval),
+            _stream(volume)), "m3d_flow_warp")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# exact order statistics (global normalisation, PixelDecoder.py:1113-1177)
+# ----------------------------------------------------------------------------
+def _key_to_float(key: int) -> float:
+    bits = (~key) & 0xFFFFFFFF if not (key & 0x80000000) else key & 0x7FFFFFFF
+    return float(np.array([bits], dtype=np.uint32).view(np.float32)[0])
+
+
+class PooledValues:
+    """A multiset of float32 voxels spread over several tensors (and, with ``group``, over
+    several ranks), optionally transformed ``max(x - sub, 0)`` and filtered ``< / > cut``
+    per tensor - the "pooled tails" of PixelDecoder.py:1113-1127 and :1144-1177."""
+
+    def __init__(self, group=None):
+        self.parts = []  # (tensor, transform, sub, filter, thr)
+        self.group = group
+
+    def add(self, values: torch.Tensor, *, sub: float | None = None, below: float | None = None,
+            above: float | None = None):
+        if values.dtype != torch.float32:
+            raise ValueError("order statistics run on float32 volumes")
+        flt, thr = (1, below) if below is not None else ((2, above) if above is not None else (0, 0.0))
+        self.parts.append((values.contiguous().view(-1), 0 if sub is None else 1,
+                           0.0 if sub is None else float(sub), flt, float(thr)))
+
+    def _hist(self, pass_idx: int, prefix: int, device) -> np.ndarray:
+        hist = torch.zeros(256, dtype=torch.int64, device=device)
+        lib = _hip.lib()
+        for values, transform, sub, flt, thr in self.parts:
+            with torch.cuda.device(values.device):
+                _hip.check(lib.m3d_radix_hist(values.data_ptr(), values.numel(), transform, sub, flt,
+                                              thr, pass_idx, prefix, hist.data_ptr(),
+                                              _stream(values)), "m3d_radix_hist")
+        if self.group is not None or _dist_ready():
+            import torch.distributed as dist
+
+            if self.group is not False:
+                dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=self.group or None)
+        return hist.cpu().numpy()
+
+    def count(self) -> int:
+        dev = self.parts[0][0].device if self.parts else "cuda"
+        return int(self._hist(0, 0, dev).sum())
+
+    def kth(self, ks) -> list[float]:
+        """Values at 0-based ranks ``ks`` of the pooled, filtered multiset (exact)."""
+        dev = self.parts[0][0].device
+        out = []
+        for k in ks:
+            prefix, rank = 0, int(k)
+            for p in range(4):
+                h = self._hist(p, prefix, dev)
+                c = np.cumsum(h)
+                b = int(np.searchsorted(c, rank, side="right"))
+                if b > 255:
+                    raise IndexError("rank beyond the number of pooled values")
+                rank -= int(c[b - 1]) if b else 0
+                prefix |= b << (24 - 8 * p)
+            out.append(_key_to_float(prefix))
+        return out
+
+    def percentile(self, q: float) -> float:
+        """``cp.percentile(x, q)`` (linear method, float64 result)."""
+        n = self.count()
+        if n == 0:
+            return float("nan")
+        idx = (float(q) / 100.0) * (n - 1)
+        lo = int(np.floor(idx))
+        hi = min(lo + 1, n - 1)
+        a, b = self.kth([lo, hi]) if hi != lo else (self.kth([lo]) * 2)
+        t = idx - lo
+        diff = b - a
+        return float(a + diff * t) if t < 0.5 else float(b - diff * (1.0 - t))
+
+    def median(self) -> float:
+        """``cp.median`` of float32 values: mean of the two middle order statistics in float32."""
+        n = self.count()
+        if n == 0:
+            return float("nan")
+        if n % 2:
+            return self.kth([n // 2])[0]
+        a, b = self.kth([n // 2 - 1, n // 2])
+        return float((np.float32(a) + np.float32(b)) / np.float32(2.0))
+
+
+def _dist_ready() -> bool:
+    try:
+        import torch.distributed as dist
+
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:
+        return False
+
+
+def replace_above(volume: torch.Tensor, threshold: float, replacement: float) -> torch.Tensor:
+    """In place ``v[v > threshold] = replacement`` (PixelDecoder.py:1072-1074)."""
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_replace_above(volume.data_ptr(), volume.numel(), float(threshold),
+                                                float(replacement), _stream(volume)),
+                   "m3d_replace_above")
+    return volume

@@ -161,6 +161,8 @@ class RLGCInfo:
     max_relative_delta: list = field(default_factory=list)
     update_min: list = field(default_factory=list)
     update_max: list = field(default_factory=list)
+    conv_ms_total: float = 0.0   # only with profile=True: device time inside fft_conv
+    conv_calls: int = 0
 
 
 def _as_device(array, device, dtype=None):
@@ -192,6 +194,7 @@ def rlgc_device(
     injected_splits=None,
     image_is_u16: bool | None = None,
     out=None,
+    profile: bool = False,
 ):
     """Device-resident RLGC: torch tensors in HBM in, float32 tensor in HBM out.
 
@@ -231,6 +234,7 @@ def rlgc_device(
         seed=int(secrets.randbits(63) if rng_seed is None else rng_seed) & 0xFFFFFFFFFFFFFFFF,
         normalize_psf=int(bool(normalize_psf)),
         max_iterations=int(max_iterations),
+        profile=int(bool(profile)),
     )
     n_inj = 0
     inj_ptr = None
@@ -271,6 +275,8 @@ def rlgc_device(
         max_relative_delta=list(result.max_relative_delta[:m]),
         update_min=list(result.update_min[:m]),
         update_max=list(result.update_max[:m]),
+        conv_ms_total=float(result.conv_ms_total),
+        conv_calls=int(result.conv_calls),
     )
     return out, info
 

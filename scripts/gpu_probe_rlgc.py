@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parents[1]))
 rl = importlib.import_module("merfish3d-analysis_amd.utils.rlgc")
 Z, Y, X = (int(v) for v in sys.argv[1:4])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
