@@ -181,6 +181,7 @@ def main() -> None:
     bits_matrix = codebook.iloc[:, 1:].to_numpy(dtype=np.int64)
     psf = gaussian_psf(psf_shape, (1.8, 1.6, 1.6), device)
     readouts, predictors, _truth = make_tile(shape, bits_matrix, n_emitters, 1 + rank, device, kernels)
+    print(f"[bench] rank {rank}: synthetic tile ready", file=sys.stderr, flush=True)
 
     store = DS.InMemoryDataStore(num_tiles=1, num_rounds=1, num_bits=n_bits, codebook=codebook)
     for b in range(n_bits):
@@ -188,7 +189,13 @@ def main() -> None:
         store.save_local_feature_predictor_image(predictors[b], tile=0, bit=b)
     decoder = PD.PixelDecoder(store, merfish_bits=n_bits, verbose=0)
     decon = torch.empty(shape, dtype=torch.float32, device=device)
-    stats = {"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0}
+    stats = {"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "fused": True,
+             "kernel_ms": [0.0] * 5}
+    t_start = time.perf_counter()
+
+    def progress(msg: str) -> None:  # keeps the GPU box's silence watchdog fed
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     def deconvolve_bits(profile: bool) -> None:
         for b in range(n_bits):  # DataRegistration._apply_bits_on_gpu: decon -> clip -> uint16
@@ -196,12 +203,17 @@ def main() -> None:
             stats["iters"] += info.iterations
             stats["conv_ms"] += info.conv_ms_total
             stats["conv_calls"] += info.conv_calls
+            stats["fused"] = info.fused_engine
+            for k in range(5):
+                stats["kernel_ms"][k] += info.kernel_ms[k]
             store.save_local_deconvolved_readout_image(kernels.clip_to_u16(decon), tile=0, bit=b)
+            progress(f"bit {b + 1}/{n_bits}: {info.iterations} RLGC iterations ({info.stop_reason})")
 
     def step(profile: bool) -> None:
         deconvolve_bits(profile)
         decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
         stats["transcripts"] = len(decoder.decoded_barcodes)
+        progress(f"decode_one_tile: {stats['transcripts']} transcripts")
 
     def fix_normalization() -> None:
         """Per-dataset analysis parameters, set once before timing: background = median and
@@ -236,8 +248,7 @@ def main() -> None:
             decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
         else:
             step(False)
-    for k in stats:
-        stats[k] = 0
+    stats.update({"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "kernel_ms": [0.0] * 5})
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -289,7 +300,9 @@ def main() -> None:
             "mvoxel_iterations_per_s": round(total_iters * n_tile / elapsed / 1e6, 2),
             "transcripts_rank0": stats["transcripts"],
             "roofline": {
-                "kernel": "fft_conv (rocFFT r2c + k_cmul + rocFFT c2r), 4 per RLGC iteration",
+                "kernel": ("fft_conv = k_x_forward + k_y_pass + k_z_conv + k_y_pass + k_x_inverse "
+                           "(fused in-LDS FFT convolution, 4 per RLGC iteration)" if stats["fused"] else
+                           "fft_conv (rocFFT r2c + k_cmul + rocFFT c2r), 4 per RLGC iteration"),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -298,8 +311,18 @@ def main() -> None:
                 "traffic": None,
                 "avg_ms": round(conv_ms, 3),
                 "launches": stats["conv_calls"],
+                "algorithmic_bytes_per_launch": RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full,
             },
         }
+        if stats["fused"] and stats["conv_calls"]:
+            # the five kernels of one convolution, with the bytes each one actually has to move
+            names = ("k_x_forward", "k_y_pass<fwd>", "k_z_conv", "k_y_pass<inv>", "k_x_inverse")
+            moved = (8.0, 8.0, 12.0, 8.0, 8.0)  # B per padded voxel (half-spectrum = 4 B / voxel)
+            out["roofline_kernels"] = [
+                {"kernel": nme, "avg_ms": round(ms / stats["conv_calls"], 3),
+                 "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
+                 "bytes_per_voxel": bpv}
+                for nme, ms, bpv in zip(names, stats["kernel_ms"], moved)]
         if world == 1 and not args.no_cpu_baseline:
             iters_per_bit = total_iters / max(args.steps * n_bits, 1)
             out["cpu_baseline"] = cpu_baseline(readouts[0], psf, bits_matrix, shape, n_bits, iters_per_bit)

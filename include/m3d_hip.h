@@ -82,10 +82,17 @@ typedef struct m3d_rlgc_result {
     double update_max[M3D_RLGC_TRACE_CAP];         /* rlgc.py:691 */
     double conv_ms_total; /* profile: summed device time of the fft_conv calls (rlgc.py:316-350) */
     int32_t conv_calls;   /* profile: number of fft_conv calls timed                          */
-    int32_t reserved2;
+    int32_t fused_engine; /* 1: in-LDS engine (kernel_ms valid), 0: rocFFT                    */
+    double kernel_ms[5];  /* profile, fused engine: summed time of k_x_forward, k_y_pass fwd,
+                             k_z_conv, k_y_pass inv, k_x_inverse over all timed convolutions  */
 } m3d_rlgc_result;
 
-/* Creates rocFFT plans for the padded shape (replaces the cuFFT plan cache +
+/* FFT engine for plans created afterwards: 0 = the fused in-LDS convolution engine
+ * (m3d_fftconv.hip; rocFFT only if a padded length cannot be handled), 1 = rocFFT. */
+int m3d_set_fft_engine(int engine);
+int m3d_rlgc_plan_uses_rocfft(const m3d_rlgc_plan *plan);
+
+/* Builds the FFT tables / plans for the padded shape (replaces the cuFFT plan cache +
  * _fft_cache_3d, rlgc.py:36-69, 340-347).  Host-synchronous. */
 int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], int pad_yx,
                          m3d_rlgc_plan **plan);

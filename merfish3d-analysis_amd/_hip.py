@@ -51,7 +51,8 @@ class RLGCResult(ctypes.Structure):
         ("update_max", ctypes.c_double * TRACE_CAP),
         ("conv_ms_total", ctypes.c_double),
         ("conv_calls", c_int32),
-        ("reserved2", c_int32),
+        ("fused_engine", c_int32),
+        ("kernel_ms", ctypes.c_double * 5),
     ]
 
 
@@ -66,6 +67,8 @@ _SIGNATURES = {
     "m3d_last_error": (c_char_p, []),
     "m3d_next_fft_size": (c_int, [c_int]),
     "m3d_rlgc_geometry": (c_int, [_I3, _I3, c_int, _I3, _I3, _I3]),
+    "m3d_set_fft_engine": (c_int, [c_int]),
+    "m3d_rlgc_plan_uses_rocfft": (c_int, [c_void_p]),
     "m3d_rlgc_plan_create": (c_int, [_I3, _I3, c_int, POINTER(c_void_p)]),
     "m3d_rlgc_plan_workspace_bytes": (c_size_t, [c_void_p]),
     "m3d_rlgc_plan_destroy": (c_int, [c_void_p]),

@@ -1,0 +1,44 @@
+// Host interface of the fused FFT-convolution engine (m3d_fftconv.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace m3d {
+
+// Optional HIP-event log (bench.py roofline): record() drops an event on the stream.
+struct EventLog {
+    std::vector<hipEvent_t> *events = nullptr;
+    size_t used = 0;
+    hipStream_t stream = nullptr;
+    bool enabled = false;
+    int record()
+    {
+        if (!enabled) return 0;
+        if (used == events->size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return -3;
+            events->push_back(e);
+        }
+        return hipEventRecord((*events)[used++], stream) == hipSuccess ? 0 : -3;
+    }
+};
+
+struct FftConvPlan;
+
+// Builds radix lists and device tables for a real volume Zp x Yp x Xp (all 2^a 3^b).
+// Returns M3D_ERR_UNSUPPORTED when a length has other factors or a pass cannot fit LDS.
+int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out);
+void fftconv_destroy(FftConvPlan *p);
+// complex elements of one tiled spectrum (>= Zp*Yp*(Xp/2+1); includes tile padding)
+int64_t fftconv_spectrum_elems(const FftConvPlan *p);
+// otf <- forward transform of the padded, centred PSF volume
+int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf, void *stream);
+// dst <- irfftn(rfftn(src) * H) with H = otf (mode 0), conj(otf) (1), |otf|^2 (2);
+// `spec` is a scratch spectrum.  src may equal dst.
+// With an enabled `log`, six events bracket the five kernels (x fwd, y fwd, z conv, y inv, x inv).
+int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
+                 float *dst, void *stream, EventLog *log = nullptr);
+
+}  // namespace m3d

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "m3d_common.h"
+#include "m3d_fftconv.h"
 #include "m3d_index.h"
 #include "m3d_philox.h"
 
@@ -451,12 +452,15 @@ struct m3d_rlgc_plan {
     rocfft_plan fwd = nullptr, inv = nullptr;
     rocfft_execution_info info_f = nullptr, info_i = nullptr;
     size_t fft_work = 0;
+    size_t spec_bytes = 0;
     size_t workspace = 0;
     // workspace offsets
     size_t o_otf, o_cbuf, o_un, o_ra, o_rb, o_hu, o_r1, o_r2, o_w1, o_w2, o_part, o_status,
         o_fftwork;
     Status *status_host = nullptr;  // pinned
     std::vector<hipEvent_t> events;  // reused across runs when params->profile is set
+    m3d::FftConvPlan *fc = nullptr;  // fused in-LDS FFT convolution engine (default)
+    void *zeroed_workspace = nullptr;  // spectrum tile padding already cleared in this buffer
 };
 
 #define M3D_ROCFFT_CHECK(expr)                                   \
@@ -470,9 +474,20 @@ struct m3d_rlgc_plan {
         }                                                        \
     } while (0)
 
+static int g_fft_engine = 0;  // 0: fused in-LDS engine (rocFFT only as fallback), 1: rocFFT
+
 extern "C" {
 
-int m3d_version(void) { return 100; }
+int m3d_version(void) { return 101; }
+
+int m3d_set_fft_engine(int engine)
+{
+    M3D_REQUIRE(engine == 0 || engine == 1, "engine must be 0 (fused) or 1 (rocFFT)");
+    g_fft_engine = engine;
+    return M3D_OK;
+}
+
+int m3d_rlgc_plan_uses_rocfft(const m3d_rlgc_plan *p) { return (p && !p->fc) ? 1 : 0; }
 
 const char *m3d_last_error(void) { return err_buf(); }
 
@@ -555,32 +570,44 @@ int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], i
     p->py = psf_zyx[1];
     p->px = psf_zyx[2];
 
-    static bool setup_done = false;
-    if (!setup_done) {
-        rocfft_setup();
-        setup_done = true;
+    // FFT engine: the fused in-LDS convolution unless rocFFT is requested (m3d_set_fft_engine)
+    // or a padded length cannot be handled (then rocFFT is the library fallback).
+    if (g_fft_engine != 1) {
+        rc = m3d::fftconv_create(g.Zp, g.Yp, g.Xp, &p->fc);
+        if (rc != M3D_OK && rc != M3D_ERR_UNSUPPORTED) {
+            set_err("fftconv_create", "table allocation failed");
+            m3d_rlgc_plan_destroy(p);
+            return rc;
+        }
     }
-    const size_t lengths[3] = {(size_t)g.Xp, (size_t)g.Yp, (size_t)g.Zp};
-    rocfft_status s;
-    s = rocfft_plan_create(&p->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
-                           rocfft_precision_single, 3, lengths, 1, nullptr);
-    if (s == rocfft_status_success)
-        s = rocfft_plan_create(&p->inv, rocfft_placement_notinplace,
-                               rocfft_transform_type_real_inverse, rocfft_precision_single, 3,
-                               lengths, 1, nullptr);
-    size_t wf = 0, wi = 0;
-    if (s == rocfft_status_success) s = rocfft_plan_get_work_buffer_size(p->fwd, &wf);
-    if (s == rocfft_status_success) s = rocfft_plan_get_work_buffer_size(p->inv, &wi);
-    if (s == rocfft_status_success) s = rocfft_execution_info_create(&p->info_f);
-    if (s == rocfft_status_success) s = rocfft_execution_info_create(&p->info_i);
-    if (s != rocfft_status_success) {
-        char b[64];
-        snprintf(b, 64, "rocfft_status %d", (int)s);
-        set_err("rocfft plan creation", b);
-        m3d_rlgc_plan_destroy(p);
-        return M3D_ERR_ROCFFT;
+    if (!p->fc) {
+        static bool setup_done = false;
+        if (!setup_done) {
+            rocfft_setup();
+            setup_done = true;
+        }
+        const size_t lengths[3] = {(size_t)g.Xp, (size_t)g.Yp, (size_t)g.Zp};
+        rocfft_status s;
+        s = rocfft_plan_create(&p->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                               rocfft_precision_single, 3, lengths, 1, nullptr);
+        if (s == rocfft_status_success)
+            s = rocfft_plan_create(&p->inv, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_inverse, rocfft_precision_single, 3,
+                                   lengths, 1, nullptr);
+        size_t wf = 0, wi = 0;
+        if (s == rocfft_status_success) s = rocfft_plan_get_work_buffer_size(p->fwd, &wf);
+        if (s == rocfft_status_success) s = rocfft_plan_get_work_buffer_size(p->inv, &wi);
+        if (s == rocfft_status_success) s = rocfft_execution_info_create(&p->info_f);
+        if (s == rocfft_status_success) s = rocfft_execution_info_create(&p->info_i);
+        if (s != rocfft_status_success) {
+            char b[64];
+            snprintf(b, 64, "rocfft_status %d", (int)s);
+            set_err("rocfft plan creation", b);
+            m3d_rlgc_plan_destroy(p);
+            return M3D_ERR_ROCFFT;
+        }
+        p->fft_work = wf > wi ? wf : wi;
     }
-    p->fft_work = wf > wi ? wf : wi;
 
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -588,7 +615,9 @@ int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], i
         off += align_up(bytes);
         return o;
     };
-    const size_t fb = sizeof(float) * (size_t)g.Np, cb = sizeof(float2) * (size_t)g.Nc;
+    const size_t fb = sizeof(float) * (size_t)g.Np;
+    const size_t cb = sizeof(float2) * (size_t)(p->fc ? m3d::fftconv_spectrum_elems(p->fc) : g.Nc);
+    p->spec_bytes = cb;
     p->o_otf = take(cb);
     p->o_cbuf = take(cb);
     p->o_un = take(fb);
@@ -624,6 +653,7 @@ int m3d_rlgc_plan_destroy(m3d_rlgc_plan *p)
     if (p->fwd) rocfft_plan_destroy(p->fwd);
     if (p->inv) rocfft_plan_destroy(p->inv);
     if (p->status_host) (void)hipHostFree(p->status_host);
+    m3d::fftconv_destroy(p->fc);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     delete p;
     return M3D_OK;
@@ -660,11 +690,18 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     Status *dstat = (Status *)(ws + p->o_status);
     void *fftwork = ws + p->o_fftwork;
 
-    M3D_ROCFFT_CHECK(rocfft_execution_info_set_stream(p->info_f, st));
-    M3D_ROCFFT_CHECK(rocfft_execution_info_set_stream(p->info_i, st));
-    if (p->fft_work) {
-        M3D_ROCFFT_CHECK(rocfft_execution_info_set_work_buffer(p->info_f, fftwork, p->fft_work));
-        M3D_ROCFFT_CHECK(rocfft_execution_info_set_work_buffer(p->info_i, fftwork, p->fft_work));
+    if (!p->fc) {
+        M3D_ROCFFT_CHECK(rocfft_execution_info_set_stream(p->info_f, st));
+        M3D_ROCFFT_CHECK(rocfft_execution_info_set_stream(p->info_i, st));
+        if (p->fft_work) {
+            M3D_ROCFFT_CHECK(rocfft_execution_info_set_work_buffer(p->info_f, fftwork, p->fft_work));
+            M3D_ROCFFT_CHECK(rocfft_execution_info_set_work_buffer(p->info_i, fftwork, p->fft_work));
+        }
+    } else if (p->zeroed_workspace != workspace) {
+        // tile padding of the two spectra (kx >= Xc in the last tile) must hold finite values
+        M3D_HIP_CHECK(hipMemsetAsync(otf, 0, p->spec_bytes, st));
+        M3D_HIP_CHECK(hipMemsetAsync(cbuf, 0, p->spec_bytes, st));
+        p->zeroed_workspace = workspace;
     }
     const float inv_n = 1.0f / (float)g.Np;
     const dim3 rb(64, kRowsPerBlock);
@@ -683,19 +720,20 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     };
     // fft_conv (rlgc.py:316-350) with H in {otf, conj(otf), |otf|^2}
     // optional HIP-event timing of every convolution (bench.py roofline; params->profile)
-    std::vector<hipEvent_t> &ev = p->events;
-    size_t ev_used = 0;
+    m3d::EventLog elog;
+    elog.events = &p->events;
+    elog.stream = st;
+    elog.enabled = params->profile != 0;
     auto stamp = [&]() -> int {
-        if (!params->profile) return M3D_OK;
-        if (ev_used == ev.size()) {
-            hipEvent_t e;
-            M3D_HIP_CHECK(hipEventCreate(&e));
-            ev.push_back(e);
+        if (elog.record()) {
+            set_err("hipEventRecord", "profiling event");
+            return M3D_ERR_HIP;
         }
-        M3D_HIP_CHECK(hipEventRecord(ev[ev_used++], st));
         return M3D_OK;
     };
     auto conv = [&](float *src, int mode, float *dst) -> int {
+        if (p->fc)  // six events per convolution: one in front of and one behind each kernel
+            return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog);
         int rc = stamp();
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
@@ -715,7 +753,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     hipLaunchKernelGGL(k_psf_embed, dim3(grid_for(npsf)), dim3(kBlock), 0, st, psf, hu, p->pz,
                        p->py, p->px, g, dstat, params->normalize_psf);
     M3D_KERNEL_CHECK();
-    if ((rc = fft_r2c(hu, otf))) return rc;
+    if (p->fc) {
+        if ((rc = m3d::fftconv_make_otf(p->fc, hu, otf, st))) return rc;
+    } else if ((rc = fft_r2c(hu, otf))) {
+        return rc;
+    }
 
     // ---- update_norm = max(conv(mask, otfT), 1e-6) (rlgc.py:587-590)
     hipLaunchKernelGGL(k_mask, dim3(g_pad), rb, 0, st, hu, g);
@@ -847,13 +889,21 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     if (res) {
         res->iterations = num_iters;
         res->stop_reason = stop;
-        res->conv_calls = (int32_t)(ev_used / 2);
+        const std::vector<hipEvent_t> &ev = p->events;
+        const size_t per = p->fc ? 6 : 2;
+        res->conv_calls = (int32_t)(elog.used / per);
         double total = 0.0;
-        for (size_t i = 0; i + 1 < ev_used; i += 2) {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) total += ms;
+        for (int k = 0; k < 5; ++k) res->kernel_ms[k] = 0.0;
+        for (size_t i = 0; i + per <= elog.used; i += per) {
+            for (size_t k = 0; k + 1 < per; ++k) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, ev[i + k], ev[i + k + 1]) != hipSuccess) continue;
+                total += ms;
+                if (p->fc) res->kernel_ms[k] += ms;
+            }
         }
         res->conv_ms_total = total;
+        res->fused_engine = p->fc ? 1 : 0;
     }
     return M3D_OK;
 }

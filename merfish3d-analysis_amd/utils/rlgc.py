@@ -129,6 +129,15 @@ def _get_plan(device_index: int, image_shape, psf_shape, pad_yx: bool) -> _Plan:
     return plan
 
 
+def set_fft_engine(engine: str = "fused") -> None:
+    """Choose the FFT engine for plans created from now on: ``"fused"`` (in-LDS convolution
+    kernels, the default) or ``"rocfft"`` (library fallback, kept for cross-checks)."""
+    if engine not in ("fused", "rocfft"):
+        raise ValueError("engine must be 'fused' or 'rocfft'")
+    clear_rlgc_caches()
+    _hip.check(_hip.lib().m3d_set_fft_engine(0 if engine == "fused" else 1), "m3d_set_fft_engine")
+
+
 def clear_rlgc_caches(clear_memory_pool: bool = False) -> None:
     """Drop cached rocFFT plans + workspaces (rlgc.py:39-69)."""
     lib = _hip.lib() if _plan_cache else None
@@ -163,6 +172,8 @@ class RLGCInfo:
     update_max: list = field(default_factory=list)
     conv_ms_total: float = 0.0   # only with profile=True: device time inside fft_conv
     conv_calls: int = 0
+    fused_engine: bool = True
+    kernel_ms: tuple = ()        # profile + fused engine: x fwd, y fwd, z conv, y inv, x inv
 
 
 def _as_device(array, device, dtype=None):
@@ -277,6 +288,8 @@ def rlgc_device(
         update_max=list(result.update_max[:m]),
         conv_ms_total=float(result.conv_ms_total),
         conv_calls=int(result.conv_calls),
+        fused_engine=bool(result.fused_engine),
+        kernel_ms=tuple(float(v) for v in result.kernel_ms),
     )
     return out, info
 

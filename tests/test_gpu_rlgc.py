@@ -140,3 +140,25 @@ def test_clip_to_u16():
     got = kernels.clip_to_u16(v).cpu().numpy()
     ref = np.clip(v.cpu().numpy(), 0, 65535).astype(np.uint16)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("shape,psf_shape", [((12, 40, 44), (7, 9, 9)), ((16, 64, 64), (9, 11, 11)),
+                                             ((5, 30, 100), (5, 7, 13)), ((1, 48, 48), (1, 9, 9))])
+def test_fused_fft_engine_matches_rocfft(shape, psf_shape):
+    """The in-LDS convolution engine against the rocFFT path on the same solver."""
+    rl = pkg("utils.rlgc")
+    rng = np.random.default_rng(5)
+    img = rng.poisson(rng.gamma(2.0, 60.0, size=shape)).astype(np.uint16)
+    zz, yy, xx = np.meshgrid(*[np.arange(n) - n // 2 for n in psf_shape], indexing="ij")
+    psf = np.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.7) ** 2 + (xx / 1.7) ** 2)).astype(np.float32)
+    try:
+        rl.set_fft_engine("rocfft")
+        ref, rinfo = rl.rlgc(img, psf, return_info=True, release_memory=False, max_iterations=12)
+        rl.set_fft_engine("fused")
+        out, info = rl.rlgc(img, psf, return_info=True, release_memory=False, max_iterations=12)
+    finally:
+        rl.set_fft_engine("fused")
+    assert info.fused_engine and not rinfo.fused_engine
+    assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
+    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=1e-4, atol=1e-7)
+    assert _rel_err(out, ref) < 2e-4
