@@ -16,6 +16,8 @@
 // digit-reversed out) and decimation-in-time inverse (digit-reversed in -> natural out).
 // The permuted order never has to be undone: the spectrum is only ever multiplied by an
 // OTF that went through the same forward pipeline.  One barrier per stage, one buffer.
+// Radices 2,3,4,8,9,16,27 (128 = 16*8, 2187 = 27*9*9); a thread owns one butterfly index
+// for up to four interleaved transforms, so twiddles and index arithmetic are shared.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -24,6 +26,14 @@
 namespace m3d {
 
 constexpr int kMaxStages = 16;
+
+// Workgroup barrier that only drains LDS traffic.  __syncthreads() also emits
+// s_waitcnt vmcnt(0), which would retire the register prefetch of the next tile (and the
+// trailing stores of the previous one) at every FFT stage and serialise HBM behind compute.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 struct AxisPlan {
     int n;                 // transform length (2^a 3^b)
@@ -49,13 +59,20 @@ __device__ __forceinline__ float2 rot90(float2 a)
 {
     return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
+// multiply by the constant exp(-+ i theta) given (cos, sin)
+template <bool INV>
+__device__ __forceinline__ float2 ctw(float2 a, float c, float s)
+{
+    return INV ? make_float2(a.x * c - a.y * s, a.x * s + a.y * c)
+               : make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
+}
 
 template <bool INV>
-__device__ __forceinline__ void dft2(float2 *v)
+__device__ __forceinline__ void dft2(float2 &a, float2 &b)
 {
-    const float2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
+    const float2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
 }
 template <bool INV>
 __device__ __forceinline__ void dft3(float2 &v0, float2 &v1, float2 &v2)
@@ -70,98 +87,224 @@ __device__ __forceinline__ void dft3(float2 &v0, float2 &v1, float2 &v2)
     v2 = csub(t2, t3);
 }
 template <bool INV>
-__device__ __forceinline__ void dft4(float2 *v)
+__device__ __forceinline__ void dft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
 {
-    const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
-    const float2 c = cadd(v[1], v[3]), d = rot90<INV>(csub(v[1], v[3]));
-    v[0] = cadd(a, c);
-    v[2] = csub(a, c);
-    v[1] = cadd(b, d);
-    v[3] = csub(b, d);
+    const float2 a = cadd(v0, v2), b = csub(v0, v2);
+    const float2 c = cadd(v1, v3), d = rot90<INV>(csub(v1, v3));
+    v0 = cadd(a, c);
+    v2 = csub(a, c);
+    v1 = cadd(b, d);
+    v3 = csub(b, d);
+}
+template <bool INV>
+__device__ __forceinline__ void dft8(float2 *v)
+{
+    // x[2a + b] -> X[c + 4d]
+    const float h = 0.70710678118654752440f;
+    dft4<INV>(v[0], v[2], v[4], v[6]);
+    dft4<INV>(v[1], v[3], v[5], v[7]);
+    v[3] = ctw<INV>(v[3], h, h);
+    v[5] = rot90<INV>(v[5]);
+    v[7] = ctw<INV>(v[7], -h, h);
+    float2 o[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float2 a = v[2 * c], b = v[2 * c + 1];
+        dft2<INV>(a, b);
+        o[c] = a;
+        o[c + 4] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = o[i];
 }
 template <bool INV>
 __device__ __forceinline__ void dft9(float2 *v)
 {
     // x[3a + b] -> X[c + 3d]
-    float2 u[3][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        u[b][0] = v[b];
-        u[b][1] = v[3 + b];
-        u[b][2] = v[6 + b];
-        dft3<INV>(u[b][0], u[b][1], u[b][2]);
-    }
-    // twiddles W9^(b*c), W9 = exp(-+ 2 pi i / 9)
-    const float c1 = 0.76604444311897803520f, s1 = 0.64278760968653932632f;
-    const float c2 = 0.17364817766693034885f, s2 = 0.98480775301220805937f;
-    const float c4 = -0.93969262078590838405f, s4 = 0.34202014332566873304f;
-    const float sg = INV ? 1.0f : -1.0f;
-    u[1][1] = cmul(u[1][1], make_float2(c1, sg * s1));
-    u[1][2] = cmul(u[1][2], make_float2(c2, sg * s2));
-    u[2][1] = cmul(u[2][1], make_float2(c2, sg * s2));
-    u[2][2] = cmul(u[2][2], make_float2(c4, sg * s4));
+    dft3<INV>(v[0], v[3], v[6]);
+    dft3<INV>(v[1], v[4], v[7]);
+    dft3<INV>(v[2], v[5], v[8]);
+    v[4] = ctw<INV>(v[4], 0.76604444311897803520f, 0.64278760968653932632f);   // W9^1
+    v[7] = ctw<INV>(v[7], 0.17364817766693034885f, 0.98480775301220805937f);   // W9^2
+    v[5] = ctw<INV>(v[5], 0.17364817766693034885f, 0.98480775301220805937f);   // W9^2
+    v[8] = ctw<INV>(v[8], -0.93969262078590838405f, 0.34202014332566873304f);  // W9^4
+    // now v[3c + b]... values u_b[c] sit at v[3c + b]; transform over b for each c
+    float2 o[9];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float2 a0 = u[0][c], a1 = u[1][c], a2 = u[2][c];
+        float2 a0 = v[3 * c], a1 = v[3 * c + 1], a2 = v[3 * c + 2];
         dft3<INV>(a0, a1, a2);
-        v[c] = a0;
-        v[c + 3] = a1;
-        v[c + 6] = a2;
+        o[c] = a0;
+        o[c + 3] = a1;
+        o[c + 6] = a2;
     }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = o[i];
+}
+template <bool INV>
+__device__ __forceinline__ void dft16(float2 *v)
+{
+    // x[4a + b] -> X[c + 4d]
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);
+    // u_b[c] sits at v[4c + b]; twiddle W16^(b c)
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
+    const float h = 0.70710678118654752440f;
+    v[4 + 1] = ctw<INV>(v[4 + 1], c1, s1);     // W^1
+    v[4 + 2] = ctw<INV>(v[4 + 2], h, h);       // W^2
+    v[4 + 3] = ctw<INV>(v[4 + 3], s1, c1);     // W^3
+    v[8 + 1] = ctw<INV>(v[8 + 1], h, h);       // W^2
+    v[8 + 2] = rot90<INV>(v[8 + 2]);           // W^4
+    v[8 + 3] = ctw<INV>(v[8 + 3], -h, h);      // W^6
+    v[12 + 1] = ctw<INV>(v[12 + 1], s1, c1);   // W^3
+    v[12 + 2] = ctw<INV>(v[12 + 2], -h, h);    // W^6
+    v[12 + 3] = ctw<INV>(v[12 + 3], -c1, -s1); // W^9
+    float2 o[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float2 a0 = v[4 * c], a1 = v[4 * c + 1], a2 = v[4 * c + 2], a3 = v[4 * c + 3];
+        dft4<INV>(a0, a1, a2, a3);
+        o[c] = a0;
+        o[c + 4] = a1;
+        o[c + 8] = a2;
+        o[c + 12] = a3;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = o[i];
+}
+template <bool INV>
+__device__ __forceinline__ void dft27(float2 *v)
+{
+    // x[9a + b] (a < 3, b < 9) -> X[c + 3d] (c < 3, d < 9)
+#pragma unroll
+    for (int b = 0; b < 9; ++b) dft3<INV>(v[b], v[9 + b], v[18 + b]);
+    // u_b[c] sits at v[9c + b]; twiddle W27^(b c)
+    const float cs[17][2] = {
+        {1.0f, 0.0f},
+        {0.97304487057982381f, 0.23061587074244017f},  {0.89363264032341228f, 0.44879918020046217f},
+        {0.76604444311897801f, 0.64278760968653925f},  {0.59715859170278618f, 0.80212319275504373f},
+        {0.39607976603915690f, 0.91821610688027400f},  {0.17364817766693041f, 0.98480775301220802f},
+        {-0.058144828910475774f, 0.99830815827126818f}, {-0.28680323271109021f, 0.95798951231548887f},
+        {-0.49999999999999978f, 0.86602540378443871f}, {-0.68624163786873349f, 0.72737364157304885f},
+        {-0.83548781141293627f, 0.54950897807080624f}, {-0.93969262078590832f, 0.34202014332566888f},
+        {-0.99323835774194302f, 0.11609291412522993f}, {-0.99323835774194302f, -0.11609291412523012f},
+        {-0.93969262078590854f, -0.34202014332566821f}, {-0.83548781141293649f, -0.54950897807080601f}};
+#pragma unroll
+    for (int b = 1; b < 9; ++b) {
+        v[9 + b] = ctw<INV>(v[9 + b], cs[b][0], cs[b][1]);
+        v[18 + b] = ctw<INV>(v[18 + b], cs[2 * b][0], cs[2 * b][1]);
+    }
+    float2 o[27];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float2 t[9];
+#pragma unroll
+        for (int b = 0; b < 9; ++b) t[b] = v[9 * c + b];
+        dft9<INV>(t);
+#pragma unroll
+        for (int d = 0; d < 9; ++d) o[c + 3 * d] = t[d];
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) v[i] = o[i];
 }
 
 template <int R, bool INV>
 __device__ __forceinline__ void dft_r(float2 *v)
 {
-    if constexpr (R == 2) dft2<INV>(v);
+    if constexpr (R == 2) dft2<INV>(v[0], v[1]);
     if constexpr (R == 3) dft3<INV>(v[0], v[1], v[2]);
-    if constexpr (R == 4) dft4<INV>(v);
+    if constexpr (R == 4) dft4<INV>(v[0], v[1], v[2], v[3]);
+    if constexpr (R == 8) dft8<INV>(v);
     if constexpr (R == 9) dft9<INV>(v);
+    if constexpr (R == 16) dft16<INV>(v);
+    if constexpr (R == 27) dft27<INV>(v);
 }
 
 // One in-place stage over `batch` interleaved transforms of length n held in LDS.
-// element k of transform b lives at data[k * estride + b * bstride]; M = current block size.
+// Element k of transform b lives at data[k * estride + b * bstride]; M = current block
+// size.  A work item = one butterfly index t for a group of G = min(batch, 4) transforms
+// (twiddles and the (block, j) split are computed once per item).  batch / G must be a
+// power of two.
 template <int R, bool INV>
 __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estride, int batch,
                                           int bstride, const float2 *__restrict__ tw, int tid,
                                           int nthreads)
 {
-    const int sub = M / R;        // butterflies per block
-    const int per_fft = n / R;    // butterflies per transform
-    const int total = per_fft * batch;
+    const int sub = M / R;      // butterflies per block
+    const int per_fft = n / R;  // butterflies per transform
     const int twstep = n / M;
+    const int G = batch < 4 ? batch : 4;
+    const int nbg = batch / G;
+    const int bshift = __builtin_ctz((unsigned)nbg);
+    const int total = per_fft << bshift;
+    const uint32_t magic = sub > 1 ? (uint32_t)(0x100000000ull / (uint32_t)sub) + 1u : 0u;
+    const int step = sub * estride;
     for (int i = tid; i < total; i += nthreads) {
-        int b, t;
-        if (bstride == 1) {  // batch-fastest: consecutive lanes touch consecutive LDS words
-            b = i % batch;
-            t = i / batch;
+        const int bg = i & (nbg - 1);
+        const int t = i >> bshift;
+        int blk, j;
+        if (sub > 1) {
+            blk = (int)__umulhi((uint32_t)t, magic);
+            j = t - blk * sub;
         } else {
-            t = i % per_fft;
-            b = i / per_fft;
+            blk = t;
+            j = 0;
         }
-        const int blk = t / sub, j = t - blk * sub;
-        float2 *p = data + (size_t)(blk * M + j) * estride + (size_t)b * bstride;
-        const int step = sub * estride;
-        float2 v[R];
+        float2 w[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = p[q * step];
-        if (INV) {
+        for (int q = 1; q < R; ++q) w[q] = tw[j * q * twstep];
+        float2 *p0 = data + (size_t)(blk * M + j) * estride + (size_t)(bg * G) * bstride;
+        // interleaved layouts (bstride == 1): lanes 8 apart sit 256 B apart = same LDS banks;
+        // rotating the member each lane starts with makes every access conflict free
+        const int rot = (bstride == 1) ? (i >> 3) : 0;
+        for (int it = 0; it < G; ++it) {
+            const int gi = (it + rot) & (G - 1);
+            float2 *p = p0 + (size_t)gi * bstride;
+            float2 v[R];
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul_conj(v[q], tw[j * q * twstep]);
-            dft_r<R, true>(v);
-        } else {
-            dft_r<R, false>(v);
+            for (int q = 0; q < R; ++q) v[q] = p[q * step];
+            if (INV) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], tw[j * q * twstep]);
+                for (int q = 1; q < R; ++q) v[q] = cmul_conj(v[q], w[q]);
+                dft_r<R, true>(v);
+            } else {
+                dft_r<R, false>(v);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) p[q * step] = v[q];
         }
-#pragma unroll
-        for (int q = 0; q < R; ++q) p[q * step] = v[q];
+    }
+}
+
+// RSET selects which butterflies a kernel is compiled with: 0 = all, 1 = lean {9,4,3,2}
+// (registers: the radix-16 butterfly alone costs ~40 VGPRs more than radix 9).
+template <bool INV, int RSET>
+__device__ __forceinline__ void lds_stage_r(int r, float2 *data, int n, int M, int estride, int batch,
+                                            int bstride, const float2 *__restrict__ tw, int tid,
+                                            int nthreads)
+{
+    switch (r) {
+#ifdef M3D_FFT_RADIX27  // costs ~180 VGPRs: halves the resident waves of every pass
+        case 27: lds_stage<27, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+#endif
+        case 16:
+            if constexpr (RSET == 0) lds_stage<16, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads);
+            break;
+        case 9: lds_stage<9, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+        case 8:
+            if constexpr (RSET == 0) lds_stage<8, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads);
+            break;
+        case 4: lds_stage<4, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+        case 3: lds_stage<3, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+        default: lds_stage<2, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
     }
 }
 
 // Full transform: DIF forward (natural -> permuted) or DIT inverse (permuted -> natural,
 // unnormalised).  Every thread of the block must call it; ends with a barrier.
-template <bool INV>
+template <bool INV, int RSET = 0>
 __device__ __forceinline__ void lds_fft(float2 *data, const AxisPlan &ap, int estride, int batch,
                                         int bstride, int tid, int nthreads)
 {
@@ -170,10 +313,7 @@ __device__ __forceinline__ void lds_fft(float2 *data, const AxisPlan &ap, int es
         int M = n;
         for (int s = 0; s < ap.nstages; ++s) {
             const int r = ap.radix[s];
-            if (r == 9) lds_stage<9, false>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
-            else if (r == 4) lds_stage<4, false>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
-            else if (r == 3) lds_stage<3, false>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
-            else lds_stage<2, false>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
+            lds_stage_r<false, RSET>(r, data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
             M /= r;
             __syncthreads();
         }
@@ -182,10 +322,7 @@ __device__ __forceinline__ void lds_fft(float2 *data, const AxisPlan &ap, int es
         for (int s = ap.nstages - 1; s >= 0; --s) {
             const int r = ap.radix[s];
             M *= r;
-            if (r == 9) lds_stage<9, true>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
-            else if (r == 4) lds_stage<4, true>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
-            else if (r == 3) lds_stage<3, true>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
-            else lds_stage<2, true>(data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
+            lds_stage_r<true, RSET>(r, data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
             __syncthreads();
         }
     }

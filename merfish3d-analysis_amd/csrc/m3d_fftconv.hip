@@ -14,7 +14,9 @@
 
 #include "m3d_fftconv.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "m3d_common.h"
@@ -33,6 +35,8 @@ struct FftConvPlan {
     AxisPlan ax, ay, az;
     void *tables = nullptr;  // one device allocation holding all twiddle / pos tables
     size_t lds_x, lds_y, lds_z;
+    int rset_x, rset_y, rset_z;  // 1: lean kernels (no radix 16 / 8 stage on that axis)
+    int ythreads, zthreads;
 };
 
 }  // namespace m3d
@@ -41,16 +45,22 @@ namespace {
 
 struct ConvGeo {
     int Zp, Yp, Xp, Xc, TW, nT, RB, P;
+    int lTW, lNB, lP;  // log2 of TW, RB/2, P (all powers of two)
     int64_t plane;
 };
 
 __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, int k)
 {
-    return (((int64_t)z * g.nT + k / g.TW) * g.Yp + y) * g.TW + (k % g.TW);
+    return ((((int64_t)z * g.nT + (k >> g.lTW)) * g.Yp + y) << g.lTW) + (k & (g.TW - 1));
 }
 
+// One tile per block; several blocks share a CU (LDS 16-70 KB each) so the load / transform /
+// store phases of different tiles overlap.  (A persistent, register-prefetching variant was
+// measured slower: hipcc spills the prefetch arrays and vmcnt is in-order)
+
 // ---------------------------------------------------------------- X forward (R2C)
-__global__ void k_x_forward(const float *__restrict__ src, float2 *__restrict__ spec, ConvGeo g,
+template <int RSET>
+__global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src, float2 *__restrict__ spec, ConvGeo g,
                             AxisPlan ax)
 {
     extern __shared__ float2 lds_fx[];
@@ -58,20 +68,21 @@ __global__ void k_x_forward(const float *__restrict__ src, float2 *__restrict__ 
     const int groups = (g.Yp + g.RB - 1) / g.RB;
     const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp;
-    for (int i = tid; i < nb * N; i += nt) {
-        const int bi = i / N, n = i - bi * N;
+    for (int bi = 0; bi < nb; ++bi) {
         const int ya = y0 + 2 * bi, yb = ya + 1;
-        const float a = ya < g.Yp ? src[((int64_t)z * g.Yp + ya) * N + n] : 0.0f;
-        const float b = yb < g.Yp ? src[((int64_t)z * g.Yp + yb) * N + n] : 0.0f;
-        lds_fx[i] = make_float2(a, b);
+        const float *ra = src + ((int64_t)z * g.Yp + ya) * N;
+        const float *rbp = ra + N;
+        const bool va = ya < g.Yp, vb = yb < g.Yp;
+        for (int n = tid; n < N; n += nt)
+            lds_fx[bi * N + n] = make_float2(va ? ra[n] : 0.0f, vb ? rbp[n] : 0.0f);
     }
     __syncthreads();
-    lds_fft<false>(lds_fx, ax, 1, nb, N, tid, nt);
+    lds_fft<false, RSET>(lds_fx, ax, 1, nb, N, tid, nt);
     // Hermitian split: A[k] = (C[k] + conj(C[N-k])) / 2, B[k] = (C[k] - conj(C[N-k])) / (2i)
-    const int total = g.nT * nb * g.TW;
+    const int total = (g.nT << g.lNB) << g.lTW;
     for (int e = tid; e < total; e += nt) {
-        const int kk = e % g.TW, bi = (e / g.TW) % nb, kt = e / (g.TW * nb);
-        const int k = kt * g.TW + kk;
+        const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+        const int k = (kt << g.lTW) + kk;
         if (k >= g.Xc) continue;
         const float2 c1 = lds_fx[bi * N + ax.pos[k]];
         const float2 c2 = lds_fx[bi * N + ax.pos[k == 0 ? 0 : N - k]];
@@ -84,7 +95,8 @@ __global__ void k_x_forward(const float *__restrict__ src, float2 *__restrict__ 
 }
 
 // ---------------------------------------------------------------- X inverse (C2R)
-__global__ void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__ dst, ConvGeo g,
+template <int RSET>
+__global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__ dst, ConvGeo g,
                             AxisPlan ax)
 {
     extern __shared__ float2 lds_ix[];
@@ -92,10 +104,10 @@ __global__ void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__
     const int groups = (g.Yp + g.RB - 1) / g.RB;
     const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp;
-    const int total = g.nT * nb * g.TW;
+    const int total = (g.nT << g.lNB) << g.lTW;
     for (int e = tid; e < total; e += nt) {
-        const int kk = e % g.TW, bi = (e / g.TW) % nb, kt = e / (g.TW * nb);
-        const int k = kt * g.TW + kk;
+        const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+        const int k = (kt << g.lTW) + kk;
         if (k >= g.Xc) continue;
         const int ya = y0 + 2 * bi;
         const float2 A = ya < g.Yp ? spec[spec_index(g, z, ya, k)] : make_float2(0.f, 0.f);
@@ -105,67 +117,79 @@ __global__ void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__
         if (k != 0 && 2 * k != N) lds_ix[bi * N + ax.pos[N - k]] = make_float2(A.x + B.y, B.x - A.y);
     }
     __syncthreads();
-    lds_fft<true>(lds_ix, ax, 1, nb, N, tid, nt);
-    for (int i = tid; i < nb * N; i += nt) {
-        const int bi = i / N, n = i - bi * N;
+    lds_fft<true, RSET>(lds_ix, ax, 1, nb, N, tid, nt);
+    for (int bi = 0; bi < nb; ++bi) {
         const int ya = y0 + 2 * bi, yb = ya + 1;
-        const float2 v = lds_ix[i];
-        if (ya < g.Yp) dst[((int64_t)z * g.Yp + ya) * N + n] = v.x;
-        if (yb < g.Yp) dst[((int64_t)z * g.Yp + yb) * N + n] = v.y;
+        float *ra = dst + ((int64_t)z * g.Yp + ya) * N;
+        float *rbp = ra + N;
+        const bool va = ya < g.Yp, vb = yb < g.Yp;
+        for (int n = tid; n < N; n += nt) {
+            const float2 v = lds_ix[bi * N + n];
+            if (va) ra[n] = v.x;
+            if (vb) rbp[n] = v.y;
+        }
     }
 }
 
 // ---------------------------------------------------------------- Y pass (in place)
-template <bool INV>
-__global__ void k_y_pass(float2 *__restrict__ spec, ConvGeo g, AxisPlan ay)
+template <bool INV, int RSET>
+__global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, ConvGeo g, AxisPlan ay)
 {
     extern __shared__ float2 lds_y[];
     const int tid = threadIdx.x, nt = blockDim.x;
     float2 *tile = spec + (int64_t)blockIdx.x * g.Yp * g.TW;  // (z, kt) tiles are consecutive
     const int n = g.Yp * g.TW;
-    for (int i = tid; i < n; i += nt) lds_y[i] = tile[i];
+    if ((n & 1) == 0) {  // 16-byte copies (tile bases are 16-B aligned when TW is even)
+        float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
+        for (int i = tid; i < n / 2; i += nt) l4[i] = t4[i];
+    } else {
+        for (int i = tid; i < n; i += nt) lds_y[i] = tile[i];
+    }
     __syncthreads();
-    lds_fft<INV>(lds_y, ay, g.TW, g.TW, 1, tid, nt);
-    for (int i = tid; i < n; i += nt) tile[i] = lds_y[i];
+    lds_fft<INV, RSET>(lds_y, ay, g.TW, g.TW, 1, tid, nt);
+    if ((n & 1) == 0) {
+        float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
+        for (int i = tid; i < n / 2; i += nt) t4[i] = l4[i];
+    } else {
+        for (int i = tid; i < n; i += nt) tile[i] = lds_y[i];
+    }
 }
 
 // ---------------------------------------------------------------- Z pass
 // mode 0: S*H  1: S*conj(H)  2: S*|H|^2  (then * scale), -1: forward only (OTF construction)
-__global__ void k_z_conv(float2 *__restrict__ spec, const float2 *__restrict__ otf, ConvGeo g,
+template <int RSET>
+__global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const float2 *__restrict__ otf, ConvGeo g,
                          AxisPlan az, int mode, float scale)
 {
     extern __shared__ float2 lds_z[];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int64_t p0 = (int64_t)blockIdx.x * g.P;
-    const int P = g.P, n = g.Zp * P;
-    for (int i = tid; i < n; i += nt) {
-        const int z = i / P, p = i - z * P;
-        lds_z[i] = (p0 + p < g.plane) ? spec[(int64_t)z * g.plane + p0 + p] : make_float2(0.f, 0.f);
-    }
+    const int P = g.P;
+    const int p = tid & (P - 1), z0 = tid >> g.lP, zstep = nt >> g.lP;  // nt is a multiple of P
+    const bool live = p0 + p < g.plane;
+    float2 *col = spec + p0 + p;
+    for (int z = z0; z < g.Zp; z += zstep)
+        lds_z[(z << g.lP) + p] = live ? col[(int64_t)z * g.plane] : make_float2(0.f, 0.f);
     __syncthreads();
-    lds_fft<false>(lds_z, az, P, P, 1, tid, nt);
+    lds_fft<false, RSET>(lds_z, az, P, P, 1, tid, nt);
     if (mode < 0) {
-        for (int i = tid; i < n; i += nt) {
-            const int z = i / P, p = i - z * P;
-            if (p0 + p < g.plane) spec[(int64_t)z * g.plane + p0 + p] = lds_z[i];
-        }
+        for (int z = z0; z < g.Zp; z += zstep)
+            if (live) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
         return;
     }
-    for (int i = tid; i < n; i += nt) {
-        const int z = i / P, p = i - z * P;
-        if (p0 + p >= g.plane) continue;
-        float2 h = otf[(int64_t)z * g.plane + p0 + p];
+    const float2 *hcol = otf + p0 + p;
+    for (int z = z0; z < g.Zp; z += zstep) {
+        if (!live) continue;
+        float2 h = hcol[(int64_t)z * g.plane];
         if (mode == 1) h.y = -h.y;
         if (mode == 2) h = make_float2(h.x * h.x + h.y * h.y, 0.0f);
-        const float2 v = cmul(lds_z[i], h);
-        lds_z[i] = make_float2(v.x * scale, v.y * scale);
+        const float2 v = cmul(lds_z[(z << g.lP) + p], h);
+        lds_z[(z << g.lP) + p] = make_float2(v.x * scale, v.y * scale);
     }
     __syncthreads();
-    lds_fft<true>(lds_z, az, P, P, 1, tid, nt);
-    for (int i = tid; i < n; i += nt) {
-        const int z = i / P, p = i - z * P;
-        if (p0 + p < g.plane) spec[(int64_t)z * g.plane + p0 + p] = lds_z[i];
-    }
+    lds_fft<true, RSET>(lds_z, az, P, P, 1, tid, nt);
+    for (int z = z0; z < g.Zp; z += zstep)
+        if (live) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
 }
 
 bool factor_23(int n, int *radix, int *nstages)
@@ -181,10 +205,29 @@ bool factor_23(int n, int *radix, int *nstages)
     }
     if (m != 1) return false;
     int s = 0;
+#ifdef M3D_FFT_RADIX27
+    if (c3 % 2 == 1 && c3 >= 3) {  // odd power of three: one radix-27 stage, the rest radix 9
+        radix[s++] = 27;
+        c3 -= 3;
+    }
+#endif
     for (int i = 0; i < c3 / 2; ++i) radix[s++] = 9;
     if (c3 % 2) radix[s++] = 3;
-    for (int i = 0; i < c2 / 2; ++i) radix[s++] = 4;
-    if (c2 % 2) radix[s++] = 2;
+    static const bool small_pow2 = getenv("M3D_FFT_BIG_RADIX") == nullptr;  // 4,4,4,2 beat 16,8 (VGPRs)
+    while (c2 >= 4 && !small_pow2) {
+        radix[s++] = 16;
+        c2 -= 4;
+    }
+    if (c2 == 3 && !small_pow2) {
+        radix[s++] = 8;
+        c2 = 0;
+    }
+    while (c2 >= 2) {
+        radix[s++] = 4;
+        c2 -= 2;
+    }
+    if (c2 == 2) radix[s++] = 4;
+    if (c2 == 1) radix[s++] = 2;
     *nstages = s;
     return s <= kMaxStages;
 }
@@ -200,6 +243,9 @@ ConvGeo geo_of(const FftConvPlan *p)
     g.nT = p->nT;
     g.RB = p->RB;
     g.P = p->P;
+    g.lTW = __builtin_ctz((unsigned)p->TW);
+    g.lNB = __builtin_ctz((unsigned)(p->RB / 2));
+    g.lP = __builtin_ctz((unsigned)p->P);
     g.plane = p->plane;
     return g;
 }
@@ -224,16 +270,31 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->ax.n = Xp;
     p->ay.n = Yp;
     p->az.n = Zp;
+    auto lean = [](const AxisPlan &a) {
+        for (int s = 0; s < a.nstages; ++s)
+            if (a.radix[s] == 16 || a.radix[s] == 8) return 0;
+        return 1;
+    };
+    p->rset_x = lean(p->ax);
+    p->rset_y = lean(p->ay);
+    p->rset_z = lean(p->az);
     // tile width: widest of 4/2/1 whose column tile fits a 72-KB LDS buffer (2 blocks / CU)
-    p->TW = 4;
+    // Tile shapes.  Defaults measured on MI355X (profiles/): knobs are for re-tuning only.
+    auto knob = [](const char *name, int dflt) {
+        const char *v = getenv(name);
+        return v ? atoi(v) : dflt;
+    };
+    p->TW = knob("M3D_FFT_TW", 4);
     while (p->TW > 1 && (size_t)Yp * p->TW * sizeof(float2) > 72 * 1024) p->TW /= 2;
     p->lds_y = (size_t)Yp * p->TW * sizeof(float2);
     // rows per X block: 4 real rows (2 packed) when they fit 40 KB, else 2
-    p->RB = ((size_t)2 * Xp * sizeof(float2) <= 40 * 1024) ? 4 : 2;
+    p->RB = ((size_t)2 * Xp * sizeof(float2) <= 40 * 1024) ? knob("M3D_FFT_RB", 4) : 2;
     p->lds_x = (size_t)(p->RB / 2) * Xp * sizeof(float2);
-    p->P = 32;
+    p->P = knob("M3D_FFT_P", 16);
     while (p->P > 1 && (size_t)Zp * p->P * sizeof(float2) > 64 * 1024) p->P /= 2;
     p->lds_z = (size_t)Zp * p->P * sizeof(float2);
+    p->ythreads = knob("M3D_FFT_YT", 768);
+    p->zthreads = std::max(p->P, knob("M3D_FFT_ZT", 128));
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -283,11 +344,17 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->ay.pos = nullptr;
     p->az.pos = nullptr;
     // allow > 64 KB of dynamic LDS where needed
-    (void)hipFuncSetAttribute((const void *)k_x_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_y_pass<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_z_conv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_z);
+    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+    (void)hipFuncSetAttribute((const void *)k_x_forward<0>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_forward<1>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<0>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<1>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass<true, 1>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_z_conv<0>, attr, (int)p->lds_z);
+    (void)hipFuncSetAttribute((const void *)k_z_conv<1>, attr, (int)p->lds_z);
     *out = p;
     return M3D_OK;
 }
@@ -307,9 +374,15 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
     const ConvGeo g = geo_of(p);
     const int groups = (p->Yp + p->RB - 1) / p->RB;
     if (log && log->record()) return M3D_ERR_HIP;
-    hipLaunchKernelGGL(k_x_forward, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
+    if (p->rset_x)
+        hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
+    else
+        hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
     if (log && log->record()) return M3D_ERR_HIP;
-    hipLaunchKernelGGL(k_y_pass<false>, dim3((unsigned)(p->Zp * p->nT)), dim3(512), p->lds_y, st, spec, g, p->ay);
+    if (p->rset_y)
+        hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+    else
+        hipLaunchKernelGGL((k_y_pass<false, 0>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -321,7 +394,10 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
     if (rc) return rc;
     const ConvGeo g = geo_of(p);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
-    hipLaunchKernelGGL(k_z_conv, dim3(nblk), dim3(256), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
+    if (p->rset_z)
+        hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
+    else
+        hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -336,12 +412,21 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
     const ConvGeo g = geo_of(p);
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
-    hipLaunchKernelGGL(k_z_conv, dim3(nblk), dim3(256), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    if (p->rset_z)
+        hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    else
+        hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
     if (log && log->record()) return M3D_ERR_HIP;
-    hipLaunchKernelGGL(k_y_pass<true>, dim3((unsigned)(p->Zp * p->nT)), dim3(512), p->lds_y, st, spec, g, p->ay);
+    if (p->rset_y)
+        hipLaunchKernelGGL((k_y_pass<true, 1>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+    else
+        hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     if (log && log->record()) return M3D_ERR_HIP;
     const int groups = (p->Yp + p->RB - 1) / p->RB;
-    hipLaunchKernelGGL(k_x_inverse, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
+    if (p->rset_x)
+        hipLaunchKernelGGL(k_x_inverse<1>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
+    else
+        hipLaunchKernelGGL(k_x_inverse<0>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
     if (log && log->record()) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;

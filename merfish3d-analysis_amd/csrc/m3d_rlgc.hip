@@ -209,7 +209,10 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
 {
     __shared__ double sm[4];
     const float eps = 1e-4f;
-    double A = 0, Bim = 0, B1 = 0, B2 = 0, Tim = 0, T1 = 0, T2 = 0;
+    // per-thread partial sums in float32 (<= a few hundred terms each), promoted to double
+    // for the cross-thread reduction: keeps the kernel HBM-bound instead of f64-VALU-bound
+    float A = 0, Bim = 0, B1 = 0, B2 = 0, Tim = 0, T1 = 0, T2 = 0;
+    double dA = 0, dBim = 0, dB1 = 0, dB2 = 0, dTim = 0, dT1 = 0, dT2 = 0;
     const int64_t rows = (int64_t)g.Z * g.Y;
     for (int64_t r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.y; r < rows;
          r += (int64_t)gridDim.x * kRowsPerBlock) {
@@ -233,32 +236,35 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
             // kl_div, rlgc.py:401-412, as raw sums (normalisers applied on the host)
             const float a = h + eps;
             const float bim = v + eps, b1 = s1 + eps, b2 = s2 + eps;
-            A += (double)a;
-            Bim += (double)bim;
-            B1 += (double)b1;
-            B2 += (double)b2;
+            A += a;
+            Bim += bim;
+            B1 += b1;
+            B2 += b2;
             if (a > 0.0f) {
-                const double la = (double)logf(a);
-                Tim += (double)a * (la - (double)logf(bim));
-                T1 += (double)a * (la - (double)logf(b1));
-                T2 += (double)a * (la - (double)logf(b2));
+                const float la = __logf(a);
+                Tim += a * (la - __logf(bim));
+                T1 += a * (la - __logf(b1));
+                T2 += a * (la - __logf(b2));
             }
             // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668
             const float den = 0.5f * (h + 1e-12f);
             r1[prow + x] = rn_div(s1, den);
             r2[prow + x] = rn_div(s2, den);
         }
+        // fold the row's float32 partials into double every row (bounded error growth)
+        dA += A; dBim += Bim; dB1 += B1; dB2 += B2; dTim += Tim; dT1 += T1; dT2 += T2;
+        A = Bim = B1 = B2 = Tim = T1 = T2 = 0.0f;
     }
     // flatten (64,4) block for the reductions
-    A = block_sum(A, sm);
-    Bim = block_sum(Bim, sm);
-    B1 = block_sum(B1, sm);
-    B2 = block_sum(B2, sm);
-    Tim = block_sum(Tim, sm);
-    T1 = block_sum(T1, sm);
-    T2 = block_sum(T2, sm);
+    dA = block_sum(dA, sm);
+    dBim = block_sum(dBim, sm);
+    dB1 = block_sum(dB1, sm);
+    dB2 = block_sum(dB2, sm);
+    dTim = block_sum(dTim, sm);
+    dT1 = block_sum(dT1, sm);
+    dT2 = block_sum(dT2, sm);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        KlPartial p = {A, Bim, B1, B2, Tim, T1, T2};
+        KlPartial p = {dA, dBim, dB1, dB2, dTim, dT1, dT2};
         partial[blockIdx.x] = p;
     }
 }

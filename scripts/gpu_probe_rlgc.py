@@ -23,8 +23,10 @@ print(f"first call (plan + 1 iter): {time.time() - t0:.2f}s padded={info.padded_
 for n in (iters, 2 * iters):
     torch.cuda.synchronize()
     t0 = time.time()
-    out, info = rl.rlgc_device(img, psf, max_iterations=n)
+    out, info = rl.rlgc_device(img, psf, max_iterations=n, profile=True)
     torch.cuda.synchronize()
     dt = time.time() - t0
-    print(f"iters={info.iterations} stop={info.stop_reason} wall={dt:.3f}s", flush=True)
+    per = [round(v / max(info.conv_calls, 1), 3) for v in info.kernel_ms]
+    print(f"iters={info.iterations} stop={info.stop_reason} wall={dt:.3f}s conv_avg_ms="
+          f"{info.conv_ms_total / max(info.conv_calls, 1):.3f} kernels(xf,yf,z,yi,xi)={per}", flush=True)
 print("mem GB", torch.cuda.max_memory_allocated() / 1e9)
