@@ -196,6 +196,41 @@ int m3d_radix_hist(const float *values, int64_t n, int transform, float sub, int
 /* image[image > threshold] = replacement, PixelDecoder.py:1072-1074 (hot pixels) */
 int m3d_replace_above(float *values, int64_t n, float threshold, float replacement, void *stream);
 
+/* Separable FIR filter with scipy boundary handling (wrap = 0: "reflect", 1: "grid-wrap"):
+ * out[i] = sum_k w[k] * in[idx(i + k - radius + offset)] per axis; radius < 0 skips an axis.
+ * Weights are host arrays of 2*radius+1 floats (radius <= 32).  Used for the cubic-spline
+ * ndi.shift(mode="grid-wrap") inside phase_cross_correlation's disambiguation: prefilter and
+ * 4-tap B-spline evaluation of a pure translation compose to one FIR per axis. */
+int m3d_separable_filter(const float *in, float *out, float *scratch, const int32_t shape_zyx[3],
+                         const float *weights_host[3], const int32_t radius[3],
+                         const int32_t offset[3], int wrap, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Phase correlation  (cucim phase_cross_correlation, utils/multiview_registration.py:265-301)
+ * ---------------------------------------------------------------------------------- */
+typedef struct m3d_fft_plan m3d_fft_plan;
+/* complex64 in-place FFT of any 1..3-D shape (slowest axis first) through rocFFT */
+int m3d_fft_plan_create(int ndim, const int32_t *shape, m3d_fft_plan **plan);
+size_t m3d_fft_plan_workspace_bytes(const m3d_fft_plan *plan);
+int m3d_fft_exec(m3d_fft_plan *plan, void *data_c64, int inverse, void *work, size_t work_bytes,
+                 void *stream); /* unnormalised */
+int m3d_fft_plan_destroy(m3d_fft_plan *plan);
+/* float32(real) -> complex64 */
+int m3d_real_to_complex(const void *in, int dtype, int64_t n, void *out_c64, void *stream);
+/* image_product = src * conj(target) [/ max(|.|, 100 eps) when normalize] */
+int m3d_cross_power(const void *src_freq, const void *target_freq, int64_t n, int normalize,
+                    void *out, void *stream);
+/* np.argmax(np.abs(x)) (first maximum); scratch >= 32 KiB; outputs are device scalars */
+int m3d_argmax_abs(const void *data_c64, int64_t n, void *scratch, int64_t *index_out,
+                   float *value_out, void *stream);
+/* out[a, r] = sum_x kernel[a, x] * (conj?) data[r, x]  - one tensordot of _upsampled_dft */
+int m3d_contract_last(const void *data_c64, int64_t rows, int32_t X, const void *kernel_c64,
+                      int32_t Ka, int conj_data, void *out_c64, void *stream);
+/* n, sum a, sum b, sum aa, sum bb, sum ab over the box [lo, hi) - np.corrcoef of one
+ * overlap tile in _disambiguate_shift */
+int m3d_box_corr_sums(const float *a, const float *b, const int32_t shape_zyx[3],
+                      const int32_t lo_zyx[3], const int32_t hi_zyx[3], double *sums6, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Resampling  (utils/multiview_registration.py)
  * ---------------------------------------------------------------------------------- */

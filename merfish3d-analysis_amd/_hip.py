@@ -98,6 +98,19 @@ _SIGNATURES = {
         [c_void_p, c_int64, c_int, c_float, c_int, ctypes.c_double, c_int, ctypes.c_uint32, c_void_p, c_void_p],
     ),
     "m3d_replace_above": (c_int, [c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "m3d_separable_filter": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, _I3, POINTER(c_void_p), _I3, _I3, c_int, c_void_p],
+    ),
+    "m3d_fft_plan_create": (c_int, [c_int, POINTER(c_int32), POINTER(c_void_p)]),
+    "m3d_fft_plan_workspace_bytes": (c_size_t, [c_void_p]),
+    "m3d_fft_exec": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "m3d_fft_plan_destroy": (c_int, [c_void_p]),
+    "m3d_real_to_complex": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p]),
+    "m3d_cross_power": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "m3d_argmax_abs": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "m3d_contract_last": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_int32, c_int, c_void_p, c_void_p]),
+    "m3d_box_corr_sums": (c_int, [c_void_p, c_void_p, _I3, _I3, _I3, c_void_p, c_void_p]),
     "m3d_max_z": (c_int, [c_void_p, c_int, _I3, c_void_p, c_void_p]),
     "m3d_affine_warp": (
         c_int,

@@ -41,8 +41,17 @@ __global__ void k_weight_readout(const uint16_t *__restrict__ readout,
 constexpr int kMaxRadius = 32;
 struct GaussW {
     int radius;
+    int offset;  // integer shift added to every tap index (0 for the Gaussian)
+    int wrap;    // 0: scipy "reflect", 1: scipy "grid-wrap" (periodic)
     float w[2 * kMaxRadius + 1];
 };
+
+__device__ __forceinline__ int tap_idx(int i, int n, int wrap)
+{
+    if (!wrap) return reflect_idx(i, n);
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
 
 // Walk one line (length len, element stride `stride`) per thread with a register window:
 // every input is read once, every output written once; lanes are adjacent lines, so all
@@ -57,9 +66,10 @@ __global__ void k_gauss_walk(const float *__restrict__ in, float *__restrict__ o
         const int64_t base = (c / inner) * outer_stride + (c % inner);
         float win[2 * R + 1];
 #pragma unroll
-        for (int k = 0; k < 2 * R; ++k) win[k] = in[base + (int64_t)reflect_idx(k - R, len) * stride];
+        for (int k = 0; k < 2 * R; ++k)
+            win[k] = in[base + (int64_t)tap_idx(k - R + gw.offset, len, gw.wrap) * stride];
         for (int t = 0; t < len; ++t) {
-            win[2 * R] = in[base + (int64_t)reflect_idx(t + R, len) * stride];
+            win[2 * R] = in[base + (int64_t)tap_idx(t + R + gw.offset, len, gw.wrap) * stride];
             float acc = 0.0f;
 #pragma unroll
             for (int k = 0; k <= 2 * R; ++k) acc = rn_fma(gw.w[k], win[k], acc);
@@ -82,7 +92,7 @@ __global__ void k_gauss_direct(const float *__restrict__ in, float *__restrict__
         for (int t = 0; t < len; ++t) {
             float acc = 0.0f;
             for (int k = 0; k <= 2 * R; ++k)
-                acc = rn_fma(gw.w[k], in[base + (int64_t)reflect_idx(t + k - R, len) * stride], acc);
+                acc = rn_fma(gw.w[k], in[base + (int64_t)tap_idx(t + k - R + gw.offset, len, gw.wrap) * stride], acc);
             out[base + (int64_t)t * stride] = acc;
         }
     }
@@ -103,7 +113,7 @@ __global__ void k_gauss_x(const float *__restrict__ in, float *__restrict__ out,
         for (int x = threadIdx.x; x < X; x += blockDim.x) {
             float acc = 0.0f;
             for (int k = 0; k <= 2 * R; ++k)
-                acc = rn_fma(gw.w[k], row_lds[reflect_idx(x + k - R, X)], acc);
+                acc = rn_fma(gw.w[k], row_lds[tap_idx(x + k - R + gw.offset, X, gw.wrap)], acc);
             dst[x] = acc;
         }
     }
@@ -113,6 +123,8 @@ GaussW make_weights(float sigma)
 {
     // scipy _gaussian_kernel1d: radius = int(truncate * sigma + 0.5), float64 weights
     GaussW gw;
+    gw.offset = 0;
+    gw.wrap = 0;
     const double sd = (double)sigma;
     int radius = (int)(4.0 * sd + 0.5);
     gw.radius = radius;
@@ -371,6 +383,56 @@ int m3d_gaussian_lowpass(const float *in, float *out, float *scratch, const int3
     const int grid = (int)(rows < 4096 ? rows : 4096);
     hipLaunchKernelGGL(k_gauss_x, dim3(grid), dim3(kBlock), (size_t)X * sizeof(float), st, cur, out,
                        rows, X, gx);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int m3d_separable_filter(const float *in, float *out, float *scratch, const int32_t shape_zyx[3],
+                         const float *weights_host[3], const int32_t radius[3],
+                         const int32_t offset[3], int wrap, void *stream)
+{
+    M3D_REQUIRE(in && out && scratch && shape_zyx && weights_host && radius && offset, "null pointer");
+    M3D_REQUIRE(scratch != in && scratch != out, "scratch must not alias in/out");
+    const int Z = shape_zyx[0], Y = shape_zyx[1], X = shape_zyx[2];
+    M3D_REQUIRE(Z > 0 && Y > 0 && X > 0, "shape must be positive");
+    M3D_REQUIRE((size_t)X * sizeof(float) <= 64 * 1024, "X extent too large for the row kernel");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t plane = (int64_t)Y * X;
+    GaussW g[3];
+    for (int a = 0; a < 3; ++a) {
+        g[a].radius = radius[a];
+        g[a].offset = offset[a];
+        g[a].wrap = wrap ? 1 : 0;
+        if (radius[a] < 0) continue;  // axis skipped
+        M3D_REQUIRE(radius[a] <= kMaxRadius && weights_host[a], "filter radius must be <= 32");
+        for (int k = 0; k < 2 * kMaxRadius + 1; ++k)
+            g[a].w[k] = k <= 2 * radius[a] ? weights_host[a][k] : 0.0f;
+    }
+    // ping-pong so the last written buffer is `out`: count the active strided axes
+    const float *cur = in;
+    const bool do_z = radius[0] >= 0, do_y = radius[1] >= 0, do_x = radius[2] >= 0;
+    auto strided = [&](int axis, float *dst) {
+        if (axis == 0)
+            gauss_strided(cur, dst, plane, plane, 0, Z, plane, g[0], st);
+        else
+            gauss_strided(cur, dst, (int64_t)Z * X, X, plane, Y, X, g[1], st);
+        cur = dst;
+    };
+    if (do_z && do_y) {
+        strided(0, scratch);
+        strided(1, out);
+    } else if (do_z || do_y) {
+        strided(do_z ? 0 : 1, (do_x || in == out) ? scratch : out);
+    }
+    if (do_x) {
+        const int64_t rows = (int64_t)Z * Y;
+        const int grid = (int)(rows < 4096 ? rows : 4096);
+        hipLaunchKernelGGL(k_gauss_x, dim3(grid), dim3(kBlock), (size_t)X * sizeof(float), st, cur, out,
+                           rows, X, g[2]);
+    } else if (cur != out) {
+        M3D_HIP_CHECK(hipMemcpyAsync(out, cur, sizeof(float) * (size_t)Z * plane,
+                                     hipMemcpyDeviceToDevice, st));
+    }
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }

@@ -359,3 +359,136 @@ def replace_above(volume: torch.Tensor, threshold: float, replacement: float) ->
                                                 float(replacement), _stream(volume)),
                    "m3d_replace_above")
     return volume
+
+
+# ----------------------------------------------------------------------------
+# phase correlation building blocks (multiview_registration.py:265-301)
+# ----------------------------------------------------------------------------
+class FFTPlan:
+    """In-place complex64 FFT of a 1..3-D tensor through ``m3d_fft_*`` (rocFFT)."""
+
+    def __init__(self, shape, device):
+        import ctypes
+
+        self.shape = tuple(int(v) for v in shape)
+        self.device = device
+        handle = ctypes.c_void_p()
+        arr = (ctypes.c_int32 * len(self.shape))(*self.shape)
+        with torch.cuda.device(device):
+            _hip.check(_hip.lib().m3d_fft_plan_create(len(self.shape), arr, ctypes.byref(handle)),
+                       "m3d_fft_plan_create")
+        self.handle = handle.value
+        nbytes = int(_hip.lib().m3d_fft_plan_workspace_bytes(self.handle))
+        self.work = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        self.work_bytes = nbytes
+
+    def execute(self, data: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+        if data.dtype != torch.complex64 or tuple(data.shape) != self.shape or not data.is_contiguous():
+            raise ValueError("FFTPlan.execute expects a contiguous complex64 tensor of the planned shape")
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().m3d_fft_exec(self.handle, data.data_ptr(), int(bool(inverse)),
+                                               self.work.data_ptr(), self.work_bytes, _stream(data)),
+                       "m3d_fft_exec")
+        return data
+
+    def close(self):
+        if self.handle:
+            _hip.lib().m3d_fft_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def real_to_complex(volume: torch.Tensor) -> torch.Tensor:
+    volume = volume.contiguous()
+    out = torch.empty(volume.shape, dtype=torch.complex64, device=volume.device)
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_real_to_complex(volume.data_ptr(), _image_dtype_code(volume),
+                                                  volume.numel(), out.data_ptr(), _stream(volume)),
+                   "m3d_real_to_complex")
+    return out
+
+
+def cross_power(src_freq: torch.Tensor, target_freq: torch.Tensor, normalize: bool = True,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(src_freq)
+    with torch.cuda.device(src_freq.device):
+        _hip.check(_hip.lib().m3d_cross_power(src_freq.data_ptr(), target_freq.data_ptr(),
+                                              src_freq.numel(), int(bool(normalize)), out.data_ptr(),
+                                              _stream(src_freq)), "m3d_cross_power")
+    return out
+
+
+def argmax_abs(data: torch.Tensor) -> int:
+    """``np.argmax(np.abs(x))`` of a complex64 tensor (flat index, first maximum)."""
+    dev = data.device
+    scratch = torch.empty(64 * 1024, dtype=torch.uint8, device=dev)
+    idx = torch.zeros(1, dtype=torch.int64, device=dev)
+    val = torch.zeros(1, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _hip.check(_hip.lib().m3d_argmax_abs(data.data_ptr(), data.numel(), scratch.data_ptr(),
+                                             idx.data_ptr(), val.data_ptr(), _stream(data)),
+                   "m3d_argmax_abs")
+    return int(idx.item())
+
+
+def contract_last(data: torch.Tensor, kernel: torch.Tensor, conj_data: bool = False) -> torch.Tensor:
+    """``np.tensordot(kernel, data, axes=(1, -1))`` for complex64 ``data[..., X]``, ``kernel[K, X]``."""
+    data = data.contiguous()
+    kernel = kernel.to(device=data.device, dtype=torch.complex64).contiguous()
+    X = int(data.shape[-1])
+    rows = data.numel() // X
+    Ka = int(kernel.shape[0])
+    out = torch.empty((Ka, *data.shape[:-1]), dtype=torch.complex64, device=data.device)
+    with torch.cuda.device(data.device):
+        _hip.check(_hip.lib().m3d_contract_last(data.data_ptr(), rows, X, kernel.data_ptr(), Ka,
+                                                int(bool(conj_data)), out.data_ptr(), _stream(data)),
+                   "m3d_contract_last")
+    return out
+
+
+def box_corr_sums(a: torch.Tensor, b: torch.Tensor, lo, hi) -> np.ndarray:
+    """(n, sum a, sum b, sum aa, sum bb, sum ab) over the box ``[lo, hi)`` of two f32 volumes."""
+    sums = torch.zeros(6, dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _hip.check(_hip.lib().m3d_box_corr_sums(a.data_ptr(), b.data_ptr(), _hip.i3(a.shape),
+                                                _hip.i3(lo), _hip.i3(hi), sums.data_ptr(), _stream(a)),
+                   "m3d_box_corr_sums")
+    return sums.cpu().numpy()
+
+
+def separable_filter(volume: torch.Tensor, weights, offsets, wrap: bool,
+                     out: torch.Tensor | None = None) -> torch.Tensor:
+    """Per-axis FIR (``weights[a]`` = 1-D array of odd length or None to skip the axis)."""
+    import ctypes
+
+    volume = volume.contiguous()
+    if out is None:
+        out = torch.empty_like(volume)
+    scratch = torch.empty_like(volume)
+    keep = []
+    ptrs = (ctypes.c_void_p * 3)()
+    radius = []
+    for a in range(3):
+        w = weights[a]
+        if w is None:
+            radius.append(-1)
+            ptrs[a] = None
+            continue
+        arr = np.ascontiguousarray(w, dtype=np.float32)
+        if arr.size % 2 != 1:
+            raise ValueError("filter length must be odd")
+        keep.append(arr)
+        ptrs[a] = arr.ctypes.data
+        radius.append((arr.size - 1) // 2)
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_separable_filter(volume.data_ptr(), out.data_ptr(), scratch.data_ptr(),
+                                                   _hip.i3(volume.shape), ptrs, _hip.i3(radius),
+                                                   _hip.i3(offsets), int(bool(wrap)), _stream(volume)),
+                   "m3d_separable_filter")
+    return out
