@@ -257,6 +257,64 @@ int m3d_flow_warp(const void *in, int dtype, const int32_t in_shape_zyx[3], void
                   const float origin_zyx_host[3], const float transform_zyx_um_host[16], int mode,
                   float cval, void *stream);
 
+/* ------------------------------------------------------------------------------------
+ * Residual flow estimation  (utils/sofima_registration.py; the arithmetic the reference
+ * delegates to the `sofima` package: flow_field.JAXMaskedXCorrWithStatsCalculator.flow_field
+ * at :676-688, mesh.relax_mesh + mesh.elastic_mesh_3d at :488-509)
+ * ---------------------------------------------------------------------------------- */
+/* like m3d_fft_plan_create with `batch` contiguous transforms per execution */
+int m3d_fft_plan_create_batched(int ndim, const int32_t *shape, int32_t batch, m3d_fft_plan **plan);
+
+/* Flow-grid nodes [node_begin, node_begin + node_count) (raster order over grid_zyx): gather the
+ * pre/post patches starting at node * step, subtract each patch mean, write pre + i*post
+ * zero-padded into complex64 [node_count, fft_z, fft_y, fft_x] (fft >= 2 * patch - 1). */
+int m3d_patch_pack(const float *pre, const float *post, const int32_t shape_zyx[3],
+                   const int32_t patch_zyx[3], const int32_t step_zyx[3], const int32_t grid_zyx[3],
+                   int64_t node_begin, int32_t node_count, const int32_t fft_zyx[3], void *out_c64,
+                   void *stream);
+/* in place on the forward transforms of m3d_patch_pack's output: spectrum of the linear
+ * cross-correlation c[d] = sum_u post(u) pre(u + d), scaled by 1/N for the unnormalised inverse */
+int m3d_patch_cross_spectrum(void *buf_c64, int32_t count, const int32_t fft_zyx[3], void *stream);
+/* per node: integer peak of the lag volume d in [-(p-1), p-1]^3 (first maximum), sharpness =
+ * peak / min within +-peak_radius, ratio = peak / best other local maximum (no larger value
+ * within +-min_distance, > threshold_rel * peak, outside the radius; 0 when none).
+ * flow_out[c * channel_stride + node_begin + i], c = x, y, z, sharpness, ratio. */
+int m3d_xcorr_peaks(const void *buf_c64, int32_t count, const int32_t fft_zyx[3],
+                    const int32_t patch_zyx[3], int32_t min_distance, int32_t peak_radius,
+                    float threshold_rel, float *flow_out, int64_t channel_stride, int64_t node_begin,
+                    void *stream);
+/* _refine_flow_vectors_subpixel, sofima_registration.py:243-417: for n (node zyx, vector xyz)
+ * pairs pick the offset triple (from n_offsets <= 5 host values per axis) minimising the mean
+ * squared difference of the normalised post patch and the order-1 sampled pre patch. */
+int m3d_subpixel_refine(const float *pre, const float *post, const int32_t shape_zyx[3],
+                        const int32_t patch_zyx[3], const int32_t step_zyx[3], const int32_t *nodes_zyx,
+                        const float *vectors_xyz, int32_t n, const float *offsets_host, int32_t n_offsets,
+                        float epsilon, float *out_xyz, void *stream);
+
+typedef struct m3d_mesh_params {
+    float dt, k0, k, stop_v_max, dt_max, start_cap, final_cap, cap_upscale;
+    int32_t num_iters, max_iters;
+} m3d_mesh_params;
+typedef struct m3d_mesh_result {
+    int32_t iterations, blocks;
+    double final_kinetic_energy;
+    float final_v_max, final_cap, final_dt, reserved;
+} m3d_mesh_result;
+size_t m3d_mesh_relax_workspace_bytes(const int32_t grid_zyx[3]);
+/* _relax_flow_field, sofima_registration.py:455-521: x [3 (xyz), gz, gy, gx] relaxed in place;
+ * prev = measured vectors (NaN = no measurement); velocity-Verlet + FIRE in blocks of num_iters */
+int m3d_mesh_relax(float *x_xyz, const float *prev_xyz, const int32_t grid_zyx[3],
+                   const float stride_xyz[3], const m3d_mesh_params *params, void *work,
+                   size_t work_bytes, m3d_mesh_result *result, void *stream);
+/* _compose_flow_fields_same_grid, sofima_registration.py:178-240 */
+int m3d_flow_compose(const float *base, const float *residual, const int32_t grid_zyx[3],
+                     const float stride_zyx[3], const float box_start_xyz[3], float *out, void *stream);
+/* _normalized_mean_squared_error, sofima_registration.py:149-175: out2 = {sum, sum of squares};
+ * out1 = sum (((a - mean_a) / scale_a) - ((b - mean_b) / scale_b))^2 */
+int m3d_moments(const float *src, int64_t n, double *out2, void *stream);
+int m3d_normalized_sq_diff(const float *a, const float *b, int64_t n, float mean_a, float scale_a,
+                           float mean_b, float scale_b, double *out1, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

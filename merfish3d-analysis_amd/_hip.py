@@ -36,6 +36,21 @@ class RLGCParams(ctypes.Structure):
     ]
 
 
+class MeshParams(ctypes.Structure):
+    _fields_ = [
+        ("dt", c_float), ("k0", c_float), ("k", c_float), ("stop_v_max", c_float), ("dt_max", c_float),
+        ("start_cap", c_float), ("final_cap", c_float), ("cap_upscale", c_float),
+        ("num_iters", c_int32), ("max_iters", c_int32),
+    ]
+
+
+class MeshResult(ctypes.Structure):
+    _fields_ = [
+        ("iterations", c_int32), ("blocks", c_int32), ("final_kinetic_energy", ctypes.c_double),
+        ("final_v_max", c_float), ("final_cap", c_float), ("final_dt", c_float), ("reserved", c_float),
+    ]
+
+
 class RLGCResult(ctypes.Structure):
     _fields_ = [
         ("iterations", c_int32),
@@ -122,6 +137,27 @@ _SIGNATURES = {
         [c_void_p, c_int, _I3, c_void_p, _I3, c_void_p, _I3, _F3, _F3, _F3, _F3, c_float * 16,
          c_int, c_float, c_void_p],
     ),
+    "m3d_fft_plan_create_batched": (c_int, [c_int, POINTER(c_int32), c_int32, POINTER(c_void_p)]),
+    "m3d_patch_pack": (c_int, [c_void_p, c_void_p, _I3, _I3, _I3, _I3, c_int64, c_int32, _I3, c_void_p, c_void_p]),
+    "m3d_patch_cross_spectrum": (c_int, [c_void_p, c_int32, _I3, c_void_p]),
+    "m3d_xcorr_peaks": (
+        c_int,
+        [c_void_p, c_int32, _I3, _I3, c_int32, c_int32, c_float, c_void_p, c_int64, c_int64, c_void_p],
+    ),
+    "m3d_subpixel_refine": (
+        c_int,
+        [c_void_p, c_void_p, _I3, _I3, _I3, c_void_p, c_void_p, c_int32, POINTER(c_float), c_int32, c_float,
+         c_void_p, c_void_p],
+    ),
+    "m3d_mesh_relax_workspace_bytes": (c_size_t, [_I3]),
+    "m3d_mesh_relax": (
+        c_int,
+        [c_void_p, c_void_p, _I3, _F3, POINTER(MeshParams), c_void_p, c_size_t, POINTER(MeshResult), c_void_p],
+    ),
+    "m3d_flow_compose": (c_int, [c_void_p, c_void_p, _I3, _F3, _F3, c_void_p, c_void_p]),
+    "m3d_moments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "m3d_normalized_sq_diff": (
+        c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -176,7 +176,13 @@ extern "C" {
 
 int m3d_fft_plan_create(int ndim, const int32_t *shape, m3d_fft_plan **out)
 {
+    return m3d_fft_plan_create_batched(ndim, shape, 1, out);
+}
+
+int m3d_fft_plan_create_batched(int ndim, const int32_t *shape, int32_t batch, m3d_fft_plan **out)
+{
     M3D_REQUIRE(out && shape && ndim >= 1 && ndim <= 3, "ndim must be 1..3");
+    M3D_REQUIRE(batch >= 1, "batch must be positive");
     size_t lengths[3];
     int64_t n = 1;
     for (int d = 0; d < ndim; ++d) {
@@ -186,7 +192,7 @@ int m3d_fft_plan_create(int ndim, const int32_t *shape, m3d_fft_plan **out)
     }
     m3d_fft_plan *p = new (std::nothrow) m3d_fft_plan();
     if (!p) return M3D_ERR_OUT_OF_MEMORY;
-    p->n = n;
+    p->n = n * batch;
     static bool setup_done = false;
     if (!setup_done) {
         rocfft_setup();
@@ -194,11 +200,12 @@ int m3d_fft_plan_create(int ndim, const int32_t *shape, m3d_fft_plan **out)
     }
     rocfft_status s = rocfft_plan_create(&p->fwd, rocfft_placement_inplace,
                                          rocfft_transform_type_complex_forward,
-                                         rocfft_precision_single, (size_t)ndim, lengths, 1, nullptr);
+                                         rocfft_precision_single, (size_t)ndim, lengths, (size_t)batch,
+                                         nullptr);
     if (s == rocfft_status_success)
         s = rocfft_plan_create(&p->inv, rocfft_placement_inplace,
                                rocfft_transform_type_complex_inverse, rocfft_precision_single,
-                               (size_t)ndim, lengths, 1, nullptr);
+                               (size_t)ndim, lengths, (size_t)batch, nullptr);
     size_t wf = 0, wi = 0;
     if (s == rocfft_status_success) s = rocfft_plan_get_work_buffer_size(p->fwd, &wf);
     if (s == rocfft_status_success) s = rocfft_plan_get_work_buffer_size(p->inv, &wi);

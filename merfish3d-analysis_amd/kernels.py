@@ -367,23 +367,27 @@ def replace_above(volume: torch.Tensor, threshold: float, replacement: float) ->
 class FFTPlan:
     """In-place complex64 FFT of a 1..3-D tensor through ``m3d_fft_*`` (rocFFT)."""
 
-    def __init__(self, shape, device):
+    def __init__(self, shape, device, batch: int = 1):
         import ctypes
 
-        self.shape = tuple(int(v) for v in shape)
+        self.batch = int(batch)
+        self.transform_shape = tuple(int(v) for v in shape)
+        self.shape = self.transform_shape if self.batch == 1 else (self.batch,) + self.transform_shape
         self.device = device
         handle = ctypes.c_void_p()
-        arr = (ctypes.c_int32 * len(self.shape))(*self.shape)
+        arr = (ctypes.c_int32 * len(self.transform_shape))(*self.transform_shape)
         with torch.cuda.device(device):
-            _hip.check(_hip.lib().m3d_fft_plan_create(len(self.shape), arr, ctypes.byref(handle)),
-                       "m3d_fft_plan_create")
+            _hip.check(_hip.lib().m3d_fft_plan_create_batched(len(self.transform_shape), arr, self.batch,
+                                                              ctypes.byref(handle)),
+                       "m3d_fft_plan_create_batched")
         self.handle = handle.value
         nbytes = int(_hip.lib().m3d_fft_plan_workspace_bytes(self.handle))
         self.work = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         self.work_bytes = nbytes
 
     def execute(self, data: torch.Tensor, inverse: bool = False) -> torch.Tensor:
-        if data.dtype != torch.complex64 or tuple(data.shape) != self.shape or not data.is_contiguous():
+        shapes = (self.shape, (self.batch,) + self.transform_shape)
+        if data.dtype != torch.complex64 or tuple(data.shape) not in shapes or not data.is_contiguous():
             raise ValueError("FFTPlan.execute expects a contiguous complex64 tensor of the planned shape")
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().m3d_fft_exec(self.handle, data.data_ptr(), int(bool(inverse)),
@@ -492,3 +496,136 @@ def separable_filter(volume: torch.Tensor, weights, offsets, wrap: bool,
                                                    _hip.i3(offsets), int(bool(wrap)), _stream(volume)),
                    "m3d_separable_filter")
     return out
+
+
+# ----------------------------------------------------------------------------
+# residual flow estimation (utils/sofima_registration.py)
+# ----------------------------------------------------------------------------
+def _i3(v):
+    import ctypes
+
+    return (ctypes.c_int32 * 3)(*[int(x) for x in v])
+
+
+def _f3(v):
+    import ctypes
+
+    return (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+def patch_pack(pre: torch.Tensor, post: torch.Tensor, patch_zyx, step_zyx, grid_zyx, node_begin: int,
+               node_count: int, fft_zyx, out: torch.Tensor) -> torch.Tensor:
+    """Mean-subtracted pre + i*post patches of ``node_count`` flow-grid nodes, zero padded."""
+    if pre.dtype != torch.float32 or post.dtype != torch.float32 or pre.shape != post.shape or pre.ndim != 3:
+        raise ValueError("patch_pack expects two float32 volumes of the same 3-D shape")
+    if out.dtype != torch.complex64 or not out.is_contiguous() or \
+            out.numel() < int(node_count) * int(np.prod([int(v) for v in fft_zyx])):
+        raise ValueError("patch_pack output must be contiguous complex64 [count, fz, fy, fx]")
+    pre, post = pre.contiguous(), post.contiguous()
+    with torch.cuda.device(pre.device):
+        _hip.check(_hip.lib().m3d_patch_pack(pre.data_ptr(), post.data_ptr(), _i3(pre.shape), _i3(patch_zyx),
+                                             _i3(step_zyx), _i3(grid_zyx), int(node_begin), int(node_count),
+                                             _i3(fft_zyx), out.data_ptr(), _stream(pre)), "m3d_patch_pack")
+    return out
+
+
+def patch_cross_spectrum(buf: torch.Tensor, count: int, fft_zyx) -> torch.Tensor:
+    with torch.cuda.device(buf.device):
+        _hip.check(_hip.lib().m3d_patch_cross_spectrum(buf.data_ptr(), int(count), _i3(fft_zyx), _stream(buf)),
+                   "m3d_patch_cross_spectrum")
+    return buf
+
+
+def xcorr_peaks(buf: torch.Tensor, count: int, fft_zyx, patch_zyx, min_distance: int, peak_radius: int,
+                threshold_rel: float, flow_out: torch.Tensor, node_begin: int) -> torch.Tensor:
+    """``flow_out`` float32 [5, nodes]: x, y, z, sharpness, ratio of nodes [node_begin, +count)."""
+    if flow_out.dtype != torch.float32 or flow_out.ndim != 2 or flow_out.shape[0] != 5 or \
+            not flow_out.is_contiguous():
+        raise ValueError("flow_out must be contiguous float32 [5, nodes]")
+    with torch.cuda.device(buf.device):
+        _hip.check(_hip.lib().m3d_xcorr_peaks(buf.data_ptr(), int(count), _i3(fft_zyx), _i3(patch_zyx),
+                                              int(min_distance), int(peak_radius), float(threshold_rel),
+                                              flow_out.data_ptr(), int(flow_out.shape[1]), int(node_begin),
+                                              _stream(buf)), "m3d_xcorr_peaks")
+    return flow_out
+
+
+def subpixel_refine(pre: torch.Tensor, post: torch.Tensor, patch_zyx, step_zyx, nodes_zyx: torch.Tensor,
+                    vectors_xyz: torch.Tensor, offsets, epsilon: float) -> torch.Tensor:
+    import ctypes
+
+    n = int(nodes_zyx.shape[0])
+    nodes_zyx = nodes_zyx.to(torch.int32).contiguous()
+    vectors_xyz = vectors_xyz.to(torch.float32).contiguous()
+    out = torch.empty_like(vectors_xyz)
+    offs = (ctypes.c_float * len(offsets))(*[float(v) for v in offsets])
+    pre, post = pre.contiguous(), post.contiguous()
+    with torch.cuda.device(pre.device):
+        _hip.check(_hip.lib().m3d_subpixel_refine(pre.data_ptr(), post.data_ptr(), _i3(pre.shape),
+                                                  _i3(patch_zyx), _i3(step_zyx), nodes_zyx.data_ptr(),
+                                                  vectors_xyz.data_ptr(), n, offs, len(offsets), float(epsilon),
+                                                  out.data_ptr(), _stream(pre)), "m3d_subpixel_refine")
+    return out
+
+
+def mesh_relax(x_xyz: torch.Tensor, prev_xyz: torch.Tensor, stride_xyz, *, dt, k0, k, stop_v_max, dt_max,
+               start_cap, final_cap, num_iters, max_iters, cap_upscale=10.0):
+    """Relax ``x_xyz`` [3, gz, gy, gx] in place; returns (x, MeshResult)."""
+    import ctypes
+
+    if x_xyz.dtype != torch.float32 or x_xyz.ndim != 4 or x_xyz.shape[0] != 3 or x_xyz.shape != prev_xyz.shape:
+        raise ValueError("mesh_relax expects float32 [3, gz, gy, gx] positions and measurements")
+    if not x_xyz.is_contiguous():
+        raise ValueError("mesh_relax positions must be contiguous (relaxed in place)")
+    prev_xyz = prev_xyz.to(torch.float32).contiguous()
+    grid = _i3(x_xyz.shape[1:])
+    nbytes = int(_hip.lib().m3d_mesh_relax_workspace_bytes(grid))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=x_xyz.device)
+    params = _hip.MeshParams(float(dt), float(k0), float(k), float(stop_v_max), float(dt_max), float(start_cap),
+                             float(final_cap), float(cap_upscale), int(num_iters), int(max_iters))
+    result = _hip.MeshResult()
+    with torch.cuda.device(x_xyz.device):
+        _hip.check(_hip.lib().m3d_mesh_relax(x_xyz.data_ptr(), prev_xyz.data_ptr(), grid, _f3(stride_xyz),
+                                             ctypes.byref(params), work.data_ptr(), nbytes, ctypes.byref(result),
+                                             _stream(x_xyz)), "m3d_mesh_relax")
+    return x_xyz, result
+
+
+def flow_compose(base: torch.Tensor, residual: torch.Tensor, stride_zyx, box_start_xyz) -> torch.Tensor:
+    base = base.to(torch.float32).contiguous()
+    residual = residual.to(torch.float32).contiguous()
+    if base.shape != residual.shape or base.ndim != 4 or base.shape[0] != 3:
+        raise ValueError("flow_compose expects two [3, gz, gy, gx] fields on the same grid")
+    out = torch.empty_like(base)
+    with torch.cuda.device(base.device):
+        _hip.check(_hip.lib().m3d_flow_compose(base.data_ptr(), residual.data_ptr(), _i3(base.shape[1:]),
+                                               _f3(stride_zyx), _f3(box_start_xyz), out.data_ptr(),
+                                               _stream(base)), "m3d_flow_compose")
+    return out
+
+
+def moments(volume: torch.Tensor) -> tuple[float, float]:
+    """(mean, population std) of a float32 tensor, double accumulation."""
+    volume = volume.contiguous()
+    if volume.dtype != torch.float32:
+        raise ValueError("moments expects float32")
+    out = torch.empty(2, dtype=torch.float64, device=volume.device)
+    with torch.cuda.device(volume.device):
+        _hip.check(_hip.lib().m3d_moments(volume.data_ptr(), volume.numel(), out.data_ptr(), _stream(volume)),
+                   "m3d_moments")
+    s, q = out.tolist()
+    n = max(volume.numel(), 1)
+    mean = s / n
+    return mean, float(np.sqrt(max(q / n - mean * mean, 0.0)))
+
+
+def normalized_sq_diff_mean(a: torch.Tensor, b: torch.Tensor, mean_a, scale_a, mean_b, scale_b) -> float:
+    a, b = a.contiguous(), b.contiguous()
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape:
+        raise ValueError("normalized_sq_diff_mean expects two float32 tensors of one shape")
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _hip.check(_hip.lib().m3d_normalized_sq_diff(a.data_ptr(), b.data_ptr(), a.numel(), float(mean_a),
+                                                     float(scale_a), float(mean_b), float(scale_b),
+                                                     out.data_ptr(), _stream(a)), "m3d_normalized_sq_diff")
+    return float(out.item()) / max(a.numel(), 1)

@@ -151,6 +151,14 @@ def install_standins() -> None:
     _mod("skimage.draw", polygon=_absent)
     _mod("skimage.measure", regionprops_table=_absent)
 
+    # jax: the reference's SOFIMA glue uses jax.numpy as an array library only (no autodiff);
+    # NumPy + scipy.ndimage.map_coordinates have the same semantics for the calls it makes
+    jnp = _mod("jax.numpy")
+    jnp.__getattr__ = lambda name: getattr(np, name)  # type: ignore[attr-defined]
+    jsp_ndi = _mod("jax.scipy.ndimage", map_coordinates=sndi.map_coordinates)
+    jsp = _mod("jax.scipy", ndimage=jsp_ndi)
+    _mod("jax", numpy=jnp, scipy=jsp, jit=lambda f: f, device_get=lambda x: x)
+
 
 def import_reference():
     install_standins()
@@ -542,12 +550,44 @@ def make_registration(mv, dw, sf):
     )
 
 
+def make_sofima_jax_glue(sf):
+    """_compose_flow_fields_same_grid / _refine_flow_vectors_subpixel
+    (sofima_registration.py:178-417) run with the NumPy/SciPy stand-in for jax."""
+    rng = np.random.default_rng(77)
+    cfg = sf.SofimaRegistrationConfig()
+    base = rng.normal(0, 2.0, size=(3, 4, 6, 7)).astype(np.float32)
+    res = rng.normal(0, 3.0, size=(3, 4, 6, 7)).astype(np.float32)
+    stride, box = (5.0, 16.0, 16.0), (16.0, 16.0, 5.0)
+    composed = sf._compose_flow_fields_same_grid(base, res, stride_zyx=stride, box_start_xyz=box)
+    # sub-pixel refinement: smooth random volume, moving = fixed sampled at a known fractional shift
+    shape, patch, step = (16, 40, 44), (6, 12, 12), (3, 6, 6)
+    fixed = sndi.gaussian_filter(rng.normal(size=shape), 1.2).astype(np.float32) * 100
+    zz, yy, xx = np.indices(shape, dtype=np.float32)
+    moving = sndi.map_coordinates(fixed, [zz - 0.5, yy + 0.5, xx - 1.5], order=1, mode="nearest").astype(np.float32)
+    grid = tuple((n - p) // s + 1 for n, p, s in zip(shape, patch, step))
+    flow = np.zeros((3,) + grid, dtype=np.float32)
+    flow[0], flow[1], flow[2] = 1.0, -1.0, 1.0
+    flow[:, 0, 1, 2] = np.nan
+    flow[:, 2, 3, 4] = np.nan
+    refined, count = sf._refine_flow_vectors_subpixel(flow, moving, fixed, patch_size_zyx=patch, step_zyx=step, config=cfg)
+    np.savez_compressed(
+        HERE / "sofima_glue_jax.npz",
+        base=base, residual=res, stride=np.asarray(stride), box_start=np.asarray(box), composed=composed,
+        fixed=fixed, moving=moving, patch=np.asarray(patch), step=np.asarray(step), flow=flow,
+        refined=refined, refined_count=np.int64(count),
+    )
+
+
 def main():
     rl, mv, dw, sf, pdm = import_reference()
+    if "--sofima-jax-only" in sys.argv:
+        make_sofima_jax_glue(sf)
+        return
     make_rlgc(rl)
     make_decode(pdm)
     make_normalization(pdm)
     make_registration(mv, dw, sf)
+    make_sofima_jax_glue(sf)
     print("golden fixtures written to", HERE)
 
 
