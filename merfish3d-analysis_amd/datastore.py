@@ -112,11 +112,24 @@ class InMemoryDataStore:
         return self._out(self._corrected[k], return_future)
 
     def _image_shape(self, tile, round=None, bit=None, kind="corrected_data"):
+        """Shape of a stored array or None; ``kind`` follows the on-disk folder names
+        (``corrected_data``, ``decon_data``, ``<feature predictor>_data``)."""
         k = self._key(tile, round, bit)
-        src = {"corrected_data": self._corrected, "registered_decon_data": self._readout_decon
-               if k and k[1] == "bit" else self._fiducial_decon}.get(kind, self._corrected)
+        if k is None:
+            return None
+        if kind == "corrected_data":
+            src = self._corrected
+        elif kind in ("decon_data", "registered_decon_data"):
+            src = self._readout_decon if k[1] == "bit" else self._fiducial_decon
+        elif kind == f"{self.feature_predictor_folder_name}_data":
+            src = self._predictor
+        else:
+            return None
         arr = src.get(k)
         return None if arr is None else tuple(int(v) for v in arr.shape)
+
+    def has_feature_predictor_spots(self, tile, bit) -> bool:
+        return self._key(tile, bit=bit) in self._predictor_spots
 
     def save_local_deconvolved_fiducial_image(self, image, tile, round, **_):
         self._fiducial_decon[self._key(tile, round=round)] = image
@@ -135,15 +148,15 @@ class InMemoryDataStore:
         arr = self._readout_decon.get(k, self._corrected.get(k))
         return None if arr is None else self._out(arr, return_future)
 
-    def save_local_feature_predictor_image(self, image, tile, bit, **_):
-        self._predictor[self._key(tile, bit=bit)] = image
+    def save_local_feature_predictor_image(self, feature_predictor_image, tile, bit, **_):
+        self._predictor[self._key(tile, bit=bit)] = feature_predictor_image
 
     def load_local_feature_predictor_image(self, tile, bit, return_future=True):
         arr = self._predictor.get(self._key(tile, bit=bit))
         return None if arr is None else self._out(arr, return_future)
 
-    def save_local_feature_predictor_spots(self, spots, tile, bit, **_):
-        self._predictor_spots[self._key(tile, bit=bit)] = spots
+    def save_local_feature_predictor_spots(self, spot_df, tile, bit, **_):
+        self._predictor_spots[self._key(tile, bit=bit)] = spot_df
 
     # ---- metadata -----------------------------------------------------------------------
     def set_round_linker(self, tile, bit, round_1based: int):
@@ -155,14 +168,16 @@ class InMemoryDataStore:
     def load_local_wavelengths_um(self, tile, round=None, bit=None):
         return self._wavelengths.get(self._key(tile, round, bit), (0.561, 0.590))
 
-    def save_local_round_transform_zyx_um(self, transform, tile, round):
-        self._round_xform[(self._tile(tile), self._round(round))] = np.asarray(transform, dtype=np.float32)
+    def save_local_round_transform_zyx_um(self, transform_zyx_um, tile, round):
+        self._round_xform[(self._tile(tile), self._round(round))] = np.asarray(transform_zyx_um, dtype=np.float32)
 
     def load_local_round_transform_zyx_um(self, tile, round):
         return self._round_xform.get((self._tile(tile), self._round(round)))
 
-    def save_local_sofima_flow_field(self, flow, tile, round, **attrs):
-        self._flow[(self._tile(tile), self._round(round))] = (np.asarray(flow, dtype=np.float32), dict(attrs))
+    def save_local_sofima_flow_field(self, sofima_flow_field_xyz_px, *, tile, round, **attrs):
+        attrs.pop("return_future", None)
+        self._flow[(self._tile(tile), self._round(round))] = (
+            np.asarray(sofima_flow_field_xyz_px, dtype=np.float32), dict(attrs))
 
     def load_local_sofima_flow_field(self, tile, round, return_future=False):
         return self._flow.get((self._tile(tile), self._round(round)))
