@@ -148,6 +148,19 @@ def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
     }
 
 
+def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tuple[float, float]:
+    """(max elapsed over ranks, total RLGC iterations over ranks) - the bench contract's timing rule."""
+    if world <= 1:
+        return float(elapsed), float(iters)
+    import torch.distributed as dist
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    it = torch.tensor([iters], dtype=torch.float64, device=device)
+    dist.all_reduce(it, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(it.item())
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,17 +268,7 @@ def main() -> None:
         step(True)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        it = torch.tensor([stats["iters"]], dtype=torch.float64, device=device)
-        dist.all_reduce(it, op=dist.ReduceOp.SUM)
-        total_iters = float(it.item())
-    else:
-        total_iters = float(stats["iters"])
+    elapsed, total_iters = aggregate_over_ranks(elapsed, stats["iters"], world, device)
 
     if rank == 0:
         n_tile = float(np.prod(shape))

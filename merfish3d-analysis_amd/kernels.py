@@ -283,7 +283,8 @@ class PooledValues:
         self.parts.append((values.contiguous().view(-1), 0 if sub is None else 1,
                            0.0 if sub is None else float(sub), flt, float(thr)))
 
-    def _hist(self, pass_idx: int, prefix: int, device) -> np.ndarray:
+    def _local_hist(self, pass_idx: int, prefix: int, device) -> torch.Tensor:
+        """This rank's 256-bin histogram of radix digit ``pass_idx`` among keys matching ``prefix``."""
         hist = torch.zeros(256, dtype=torch.int64, device=device)
         lib = _hip.lib()
         for values, transform, sub, flt, thr in self.parts:
@@ -291,6 +292,10 @@ class PooledValues:
                 _hip.check(lib.m3d_radix_hist(values.data_ptr(), values.numel(), transform, sub, flt,
                                               thr, pass_idx, prefix, hist.data_ptr(),
                                               _stream(values)), "m3d_radix_hist")
+        return hist
+
+    def _hist(self, pass_idx: int, prefix: int, device) -> np.ndarray:
+        hist = self._local_hist(pass_idx, prefix, device)
         if self.group is not None or _dist_ready():
             import torch.distributed as dist
 
