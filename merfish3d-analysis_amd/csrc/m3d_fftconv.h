@@ -27,6 +27,14 @@ struct EventLog {
 
 struct FftConvPlan;
 
+// Support box (z, y, x offsets and extents in the padded volume).  As `in_box`: src is zero
+// outside it, so rows / planes outside are neither read nor transformed.  As `out_box`: only
+// that part of dst is needed, so the inverse passes skip everything else (dst keeps stale
+// values outside the box).
+struct ConvBox {
+    int z0, nz, y0, ny, x0, nx;
+};
+
 // Builds radix lists and device tables for a real volume Zp x Yp x Xp (all 2^a 3^b).
 // Returns M3D_ERR_UNSUPPORTED when a length has other factors or a pass cannot fit LDS.
 int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out);
@@ -39,6 +47,7 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
 // `spec` is a scratch spectrum.  src may equal dst.
 // With an enabled `log`, six events bracket the five kernels (x fwd, y fwd, z conv, y inv, x inv).
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
-                 float *dst, void *stream, EventLog *log = nullptr);
+                 float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
+                 const ConvBox *out_box = nullptr);
 
 }  // namespace m3d

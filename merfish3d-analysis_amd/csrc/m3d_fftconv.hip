@@ -1,4 +1,6 @@
-// Fused 3-D FFT convolution for RLGC on MI355X: 5 kernels, 44 B of HBM traffic per voxel.
+// Fused 3-D FFT convolution for RLGC on MI355X: 5 kernels, 44 B of HBM traffic per voxel
+// (34 B when the input is zero outside the observed core, or only the core of the output is
+// needed - every RLGC convolution is one or the other; see ConvBox).
 //
 //   k_x_forward   two real rows -> one packed complex FFT (in LDS) -> two Hermitian half rows,
 //                 written into the tiled spectrum  S[z][kx/TW][y][kx%TW]      (r 4 B, w 4 B)
@@ -47,6 +49,7 @@ struct ConvGeo {
     int Zp, Yp, Xp, Xc, TW, nT, RB, P;
     int lTW, lNB, lP;  // log2 of TW, RB/2, P (all powers of two)
     int64_t plane;
+    m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
 };
 
 __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, int k)
@@ -65,16 +68,20 @@ __global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src
 {
     extern __shared__ float2 lds_fx[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int groups = (g.Yp + g.RB - 1) / g.RB;
-    const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * g.RB;
+    // row groups start on a multiple of RB so the pairing of rows does not depend on the box
+    const int yg0 = (g.in.y0 / g.RB) * g.RB, y_hi = g.in.y0 + g.in.ny, x_hi = g.in.x0 + g.in.nx;
+    const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
+    const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp;
     for (int bi = 0; bi < nb; ++bi) {
         const int ya = y0 + 2 * bi, yb = ya + 1;
         const float *ra = src + ((int64_t)z * g.Yp + ya) * N;
         const float *rbp = ra + N;
-        const bool va = ya < g.Yp, vb = yb < g.Yp;
-        for (int n = tid; n < N; n += nt)
-            lds_fx[bi * N + n] = make_float2(va ? ra[n] : 0.0f, vb ? rbp[n] : 0.0f);
+        const bool va = ya >= g.in.y0 && ya < y_hi, vb = yb >= g.in.y0 && yb < y_hi;
+        for (int n = tid; n < N; n += nt) {
+            const bool vx = n >= g.in.x0 && n < x_hi;
+            lds_fx[bi * N + n] = make_float2(va && vx ? ra[n] : 0.0f, vb && vx ? rbp[n] : 0.0f);
+        }
     }
     __syncthreads();
     lds_fft<false, RSET>(lds_fx, ax, 1, nb, N, tid, nt);
@@ -88,9 +95,9 @@ __global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src
         const float2 c2 = lds_fx[bi * N + ax.pos[k == 0 ? 0 : N - k]];
         const float2 A = make_float2(0.5f * (c1.x + c2.x), 0.5f * (c1.y - c2.y));
         const float2 B = make_float2(0.5f * (c1.y + c2.y), 0.5f * (c2.x - c1.x));
-        const int ya = y0 + 2 * bi;
-        if (ya < g.Yp) spec[spec_index(g, z, ya, k)] = A;
-        if (ya + 1 < g.Yp) spec[spec_index(g, z, ya + 1, k)] = B;
+        const int ya = y0 + 2 * bi;  // rows outside the box are zero-filled by the Y pass
+        if (ya >= g.in.y0 && ya < y_hi) spec[spec_index(g, z, ya, k)] = A;
+        if (ya + 1 >= g.in.y0 && ya + 1 < y_hi) spec[spec_index(g, z, ya + 1, k)] = B;
     }
 }
 
@@ -101,17 +108,19 @@ __global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ sp
 {
     extern __shared__ float2 lds_ix[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int groups = (g.Yp + g.RB - 1) / g.RB;
-    const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * g.RB;
+    const int yg0 = (g.out.y0 / g.RB) * g.RB, y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
+    const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
+    const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp;
     const int total = (g.nT << g.lNB) << g.lTW;
     for (int e = tid; e < total; e += nt) {
         const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
         const int k = (kt << g.lTW) + kk;
         if (k >= g.Xc) continue;
-        const int ya = y0 + 2 * bi;
-        const float2 A = ya < g.Yp ? spec[spec_index(g, z, ya, k)] : make_float2(0.f, 0.f);
-        const float2 B = ya + 1 < g.Yp ? spec[spec_index(g, z, ya + 1, k)] : make_float2(0.f, 0.f);
+        const int ya = y0 + 2 * bi;  // rows outside the box were not produced by the Y pass
+        const float2 A = ya >= g.out.y0 && ya < y_hi ? spec[spec_index(g, z, ya, k)] : make_float2(0.f, 0.f);
+        const float2 B =
+            ya + 1 >= g.out.y0 && ya + 1 < y_hi ? spec[spec_index(g, z, ya + 1, k)] : make_float2(0.f, 0.f);
         // C[k] = A + iB ; C[N-k] = conj(A) + i conj(B)
         lds_ix[bi * N + ax.pos[k]] = make_float2(A.x - B.y, A.y + B.x);
         if (k != 0 && 2 * k != N) lds_ix[bi * N + ax.pos[N - k]] = make_float2(A.x + B.y, B.x - A.y);
@@ -122,8 +131,8 @@ __global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ sp
         const int ya = y0 + 2 * bi, yb = ya + 1;
         float *ra = dst + ((int64_t)z * g.Yp + ya) * N;
         float *rbp = ra + N;
-        const bool va = ya < g.Yp, vb = yb < g.Yp;
-        for (int n = tid; n < N; n += nt) {
+        const bool va = ya >= g.out.y0 && ya < y_hi, vb = yb >= g.out.y0 && yb < y_hi;
+        for (int n = g.out.x0 + tid; n < x_hi; n += nt) {
             const float2 v = lds_ix[bi * N + n];
             if (va) ra[n] = v.x;
             if (vb) rbp[n] = v.y;
@@ -137,21 +146,28 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
 {
     extern __shared__ float2 lds_y[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    float2 *tile = spec + (int64_t)blockIdx.x * g.Yp * g.TW;  // (z, kt) tiles are consecutive
+    // forward: only the input's z planes hold data, rows outside its y range are zero;
+    // inverse: only the output's z planes are transformed and only its y rows are stored
+    const m3d::ConvBox &bx = INV ? g.out : g.in;
+    const int z = bx.z0 + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
+    float2 *tile = spec + ((int64_t)z * g.nT + kt) * g.Yp * g.TW;  // (z, kt) tiles are consecutive
     const int n = g.Yp * g.TW;
-    if ((n & 1) == 0) {  // 16-byte copies (tile bases are 16-B aligned when TW is even)
+    const int lo = INV ? 0 : bx.y0 * g.TW, hi = INV ? n : (bx.y0 + bx.ny) * g.TW;  // load range
+    const int slo = INV ? bx.y0 * g.TW : 0, shi = INV ? (bx.y0 + bx.ny) * g.TW : n;  // store range
+    if ((g.TW & 1) == 0) {  // 16-byte copies (tile bases are 16-B aligned when TW is even)
         float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
-        for (int i = tid; i < n / 2; i += nt) l4[i] = t4[i];
+        for (int i = tid; i < n / 2; i += nt)
+            l4[i] = (i >= lo / 2 && i < hi / 2) ? t4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-        for (int i = tid; i < n; i += nt) lds_y[i] = tile[i];
+        for (int i = tid; i < n; i += nt) lds_y[i] = (i >= lo && i < hi) ? tile[i] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     lds_fft<INV, RSET>(lds_y, ay, g.TW, g.TW, 1, tid, nt);
-    if ((n & 1) == 0) {
+    if ((g.TW & 1) == 0) {
         float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
-        for (int i = tid; i < n / 2; i += nt) t4[i] = l4[i];
+        for (int i = slo / 2 + tid; i < shi / 2; i += nt) t4[i] = l4[i];
     } else {
-        for (int i = tid; i < n; i += nt) tile[i] = lds_y[i];
+        for (int i = slo + tid; i < shi; i += nt) tile[i] = lds_y[i];
     }
 }
 
@@ -168,8 +184,9 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
     const int p = tid & (P - 1), z0 = tid >> g.lP, zstep = nt >> g.lP;  // nt is a multiple of P
     const bool live = p0 + p < g.plane;
     float2 *col = spec + p0 + p;
-    for (int z = z0; z < g.Zp; z += zstep)
-        lds_z[(z << g.lP) + p] = live ? col[(int64_t)z * g.plane] : make_float2(0.f, 0.f);
+    for (int z = z0; z < g.Zp; z += zstep)  // planes outside the input's support are zero
+        lds_z[(z << g.lP) + p] = live && z >= g.in.z0 && z < g.in.z0 + g.in.nz ? col[(int64_t)z * g.plane]
+                                                                                : make_float2(0.f, 0.f);
     __syncthreads();
     lds_fft<false, RSET>(lds_z, az, P, P, 1, tid, nt);
     if (mode < 0) {
@@ -188,8 +205,8 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
     }
     __syncthreads();
     lds_fft<true, RSET>(lds_z, az, P, P, 1, tid, nt);
-    for (int z = z0; z < g.Zp; z += zstep)
-        if (live) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
+    for (int z = z0; z < g.Zp; z += zstep)  // only the planes the output needs
+        if (live && z >= g.out.z0 && z < g.out.z0 + g.out.nz) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
 }
 
 bool factor_23(int n, int *radix, int *nstages)
@@ -232,9 +249,12 @@ bool factor_23(int n, int *radix, int *nstages)
     return s <= kMaxStages;
 }
 
-ConvGeo geo_of(const FftConvPlan *p)
+ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d::ConvBox *out = nullptr)
 {
     ConvGeo g;
+    const m3d::ConvBox full = {0, p->Zp, 0, p->Yp, 0, p->Xp};
+    g.in = in ? *in : full;
+    g.out = out ? *out : full;
     g.Zp = p->Zp;
     g.Yp = p->Yp;
     g.Xp = p->Xp;
@@ -368,21 +388,27 @@ void fftconv_destroy(FftConvPlan *p)
 
 int64_t fftconv_spectrum_elems(const FftConvPlan *p) { return (int64_t)p->Zp * p->plane; }
 
-static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
-                             EventLog *log = nullptr)
+static int row_groups(const FftConvPlan *p, const m3d::ConvBox &b)
 {
-    const ConvGeo g = geo_of(p);
-    const int groups = (p->Yp + p->RB - 1) / p->RB;
+    const int yg0 = (b.y0 / p->RB) * p->RB;
+    return (b.y0 + b.ny - yg0 + p->RB - 1) / p->RB;
+}
+
+static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
+                             EventLog *log = nullptr, const ConvBox *in_box = nullptr)
+{
+    const ConvGeo g = geo_of(p, in_box);
+    const int groups = row_groups(p, g.in);
     if (log && log->record()) return M3D_ERR_HIP;
     if (p->rset_x)
-        hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
+        hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
     else
-        hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
+        hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
     if (log && log->record()) return M3D_ERR_HIP;
     if (p->rset_y)
-        hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+        hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     else
-        hipLaunchKernelGGL((k_y_pass<false, 0>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+        hipLaunchKernelGGL((k_y_pass<false, 0>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -402,14 +428,21 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
     return M3D_OK;
 }
 
+static bool box_ok(const FftConvPlan *p, const ConvBox *b)
+{
+    return !b || (b->z0 >= 0 && b->nz > 0 && b->z0 + b->nz <= p->Zp && b->y0 >= 0 && b->ny > 0 &&
+                  b->y0 + b->ny <= p->Yp && b->x0 >= 0 && b->nx > 0 && b->x0 + b->nx <= p->Xp);
+}
+
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
-                 float *dst, void *stream, EventLog *log)
+                 float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box)
 {
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_forward_xy(p, src, spec, st, log);
+    if (!box_ok(p, in_box) || !box_ok(p, out_box)) return M3D_ERR_INVALID_ARG;
+    int rc = launch_forward_xy(p, src, spec, st, log, in_box);
     if (rc) return rc;
     if (log && log->record()) return M3D_ERR_HIP;
-    const ConvGeo g = geo_of(p);
+    const ConvGeo g = geo_of(p, in_box, out_box);
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
     if (p->rset_z)
@@ -418,15 +451,15 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
     if (log && log->record()) return M3D_ERR_HIP;
     if (p->rset_y)
-        hipLaunchKernelGGL((k_y_pass<true, 1>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+        hipLaunchKernelGGL((k_y_pass<true, 1>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     else
-        hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+        hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     if (log && log->record()) return M3D_ERR_HIP;
-    const int groups = (p->Yp + p->RB - 1) / p->RB;
+    const int groups = row_groups(p, g.out);
     if (p->rset_x)
-        hipLaunchKernelGGL(k_x_inverse<1>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
+        hipLaunchKernelGGL(k_x_inverse<1>, dim3((unsigned)(g.out.nz * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
     else
-        hipLaunchKernelGGL(k_x_inverse<0>, dim3((unsigned)(p->Zp * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
+        hipLaunchKernelGGL(k_x_inverse<0>, dim3((unsigned)(g.out.nz * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
     if (log && log->record()) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;

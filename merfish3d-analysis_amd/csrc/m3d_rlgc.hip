@@ -30,6 +30,7 @@
 #include <rocfft/rocfft.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -737,9 +738,17 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         }
         return M3D_OK;
     };
-    auto conv = [&](float *src, int mode, float *dst) -> int {
+    // Every convolution of the iteration either takes an input that is zero outside the observed
+    // core (mask, ratio volumes) or produces an output that is only read inside it (Hu, consensus
+    // map): the engine skips the rows / planes that carry nothing (M3D_FFT_PRUNE=0 disables).
+    const bool prune = !(getenv("M3D_FFT_PRUNE") && atoi(getenv("M3D_FFT_PRUNE")) == 0);
+    const m3d::ConvBox core = {g.bz, g.Z, g.by, g.Y, g.bx, g.X};
+    enum { kFull = 0, kInCore = 1, kOutCore = 2 };
+    auto conv = [&](float *src, int mode, float *dst, int support = kFull) -> int {
         if (p->fc)  // six events per convolution: one in front of and one behind each kernel
-            return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog);
+            return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog,
+                                     prune && support == kInCore ? &core : nullptr,
+                                     prune && support == kOutCore ? &core : nullptr);
         int rc = stamp();
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
@@ -768,7 +777,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     // ---- update_norm = max(conv(mask, otfT), 1e-6) (rlgc.py:587-590)
     hipLaunchKernelGGL(k_mask, dim3(g_pad), rb, 0, st, hu, g);
     M3D_KERNEL_CHECK();
-    if ((rc = conv(hu, 1, un))) return rc;
+    if ((rc = conv(hu, 1, un, kInCore))) return rc;
     hipLaunchKernelGGL(k_floor, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, un, 1e-6f, g.Np);
 
     // ---- recon = mean(observed) everywhere (rlgc.py:600-603)
@@ -789,7 +798,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
 
     auto enqueue_forward = [&](int it) -> int {
-        int rc2 = conv(recon_cur, 0, hu);  // Hu, rlgc.py:624
+        int rc2 = conv(recon_cur, 0, hu, kOutCore);  // Hu, rlgc.py:624 (read on the core only)
         if (rc2) return rc2;
         const float *inj =
             (injected && it < n_injected) ? injected + (size_t)it * (size_t)g.N : nullptr;
@@ -807,11 +816,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     };
     auto enqueue_update = [&]() -> int {
         int rc2;
-        if ((rc2 = conv(r1, 1, w1))) return rc2;  // HTratio1 * update_norm, rlgc.py:654-662
-        if ((rc2 = conv(r2, 1, w2))) return rc2;  // rlgc.py:664-672
+        if ((rc2 = conv(r1, 1, w1, kInCore))) return rc2;  // HTratio1 * update_norm, rlgc.py:654-662
+        if ((rc2 = conv(r2, 1, w2, kInCore))) return rc2;  // rlgc.py:664-672
         hipLaunchKernelGGL(k_consensus_in, dim3(g_pad), rb, 0, st, w1, w2, un, hu, g, mm_part);
         M3D_KERNEL_CHECK();
-        if ((rc2 = conv(hu, 2, w2))) return rc2;  // consensus_map, rlgc.py:677-679
+        if ((rc2 = conv(hu, 2, w2, kOutCore))) return rc2;  // consensus_map, rlgc.py:677-679 (core only)
         hipLaunchKernelGGL(k_update, dim3(g_core), rb, 0, st, w2, recon_cur, w1, recon_prev, g,
                            up_part);
         hipLaunchKernelGGL(k_boundary, dim3(g_pad), rb, 0, st, recon_prev, g);
