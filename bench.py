@@ -320,11 +320,19 @@ def main() -> None:
         if stats["fused"] and stats["conv_calls"]:
             # the five kernels of one convolution, with the bytes each one actually has to move
             names = ("k_x_forward", "k_y_pass<fwd>", "k_z_conv", "k_y_pass<inv>", "k_x_inverse")
-            moved = (8.0, 8.0, 12.0, 8.0, 8.0)  # B per padded voxel (half-spectrum = 4 B / voxel)
+            # B per padded voxel each kernel has to move (half-spectrum = 4 B / voxel), averaged
+            # over the two kinds of convolution in an iteration: input zero outside the core
+            # (2 of 4) and output read on the core only (2 of 4) - see ConvBox in m3d_fftconv.h
+            fz, fy, fx = (shape[i] / padded[i] for i in range(3))
+            rows, vox = fz * fy, fz * fy * fx
+            x_small = 4.0 * vox + 4.0 * rows   # real rows of the core <-> their half spectra
+            y_small = 4.0 * rows + 4.0 * fz    # core z planes: core y rows <-> all ky
+            moved = ((x_small + 8.0) / 2, (y_small + 8.0) / 2, 4.0 + 4.0 + 4.0 * fz, (y_small + 8.0) / 2,
+                     (x_small + 8.0) / 2)
             out["roofline_kernels"] = [
                 {"kernel": nme, "avg_ms": round(ms / stats["conv_calls"], 3),
                  "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
-                 "bytes_per_voxel": bpv}
+                 "bytes_per_voxel": round(bpv, 2)}
                 for nme, ms, bpv in zip(names, stats["kernel_ms"], moved)]
         if world == 1 and not args.no_cpu_baseline:
             iters_per_bit = total_iters / max(args.steps * n_bits, 1)

@@ -26,6 +26,17 @@
 
 using namespace m3d;
 
+// loads kept in flight per thread in the load phase of each pass (measured on MI355X)
+#ifndef M3D_KU_Z
+#define M3D_KU_Z 8
+#endif
+#ifndef M3D_KU_Y
+#define M3D_KU_Y 3
+#endif
+#ifndef M3D_KU_XI
+#define M3D_KU_XI 9
+#endif
+
 namespace m3d {
 
 struct FftConvPlan {
@@ -73,31 +84,56 @@ __global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp;
+    constexpr int kU = 3;   // batch of the table loads below (see k_z_conv)
+    constexpr int kUL = 9;  // row loads are 4 bytes per lane: a whole 2187-sample row pair per batch
     for (int bi = 0; bi < nb; ++bi) {
         const int ya = y0 + 2 * bi, yb = ya + 1;
-        const float *ra = src + ((int64_t)z * g.Yp + ya) * N;
-        const float *rbp = ra + N;
         const bool va = ya >= g.in.y0 && ya < y_hi, vb = yb >= g.in.y0 && yb < y_hi;
-        for (int n = tid; n < N; n += nt) {
-            const bool vx = n >= g.in.x0 && n < x_hi;
-            lds_fx[bi * N + n] = make_float2(va && vx ? ra[n] : 0.0f, vb && vx ? rbp[n] : 0.0f);
+        const float *ra = src + ((int64_t)z * g.Yp + (va ? ya : g.in.y0)) * N;
+        const float *rbp = src + ((int64_t)z * g.Yp + (vb ? yb : g.in.y0)) * N;
+        for (int n0 = tid; n0 < N; n0 += nt * kUL) {
+            float a[kUL], b[kUL];
+#pragma unroll
+            for (int u = 0; u < kUL; ++u) {
+                const int n = min(n0 + u * nt, N - 1);
+                a[u] = ra[n];
+                b[u] = rbp[n];
+            }
+#pragma unroll
+            for (int u = 0; u < kUL; ++u) {
+                const int n = n0 + u * nt;
+                const bool vx = n >= g.in.x0 && n < x_hi;
+                if (n < N) lds_fx[bi * N + n] = make_float2(va && vx ? a[u] : 0.0f, vb && vx ? b[u] : 0.0f);
+            }
         }
     }
     __syncthreads();
     lds_fft<false, RSET>(lds_fx, ax, 1, nb, N, tid, nt);
     // Hermitian split: A[k] = (C[k] + conj(C[N-k])) / 2, B[k] = (C[k] - conj(C[N-k])) / (2i)
     const int total = (g.nT << g.lNB) << g.lTW;
-    for (int e = tid; e < total; e += nt) {
-        const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
-        const int k = (kt << g.lTW) + kk;
-        if (k >= g.Xc) continue;
-        const float2 c1 = lds_fx[bi * N + ax.pos[k]];
-        const float2 c2 = lds_fx[bi * N + ax.pos[k == 0 ? 0 : N - k]];
-        const float2 A = make_float2(0.5f * (c1.x + c2.x), 0.5f * (c1.y - c2.y));
-        const float2 B = make_float2(0.5f * (c1.y + c2.y), 0.5f * (c2.x - c1.x));
-        const int ya = y0 + 2 * bi;  // rows outside the box are zero-filled by the Y pass
-        if (ya >= g.in.y0 && ya < y_hi) spec[spec_index(g, z, ya, k)] = A;
-        if (ya + 1 >= g.in.y0 && ya + 1 < y_hi) spec[spec_index(g, z, ya + 1, k)] = B;
+    for (int e0 = tid; e0 < total; e0 += nt * kU) {
+        int p1[kU], p2[kU];  // digit-reversed positions of k and N-k, fetched as one batch
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = min(e0 + u * nt, total - 1);
+            const int k = min(((e >> (g.lTW + g.lNB)) << g.lTW) + (e & (g.TW - 1)), g.Xc - 1);
+            p1[u] = ax.pos[k];
+            p2[u] = ax.pos[k == 0 ? 0 : N - k];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + u * nt;
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int k = (kt << g.lTW) + kk;
+            if (e >= total || k >= g.Xc) continue;
+            const float2 c1 = lds_fx[bi * N + p1[u]];
+            const float2 c2 = lds_fx[bi * N + p2[u]];
+            const float2 A = make_float2(0.5f * (c1.x + c2.x), 0.5f * (c1.y - c2.y));
+            const float2 B = make_float2(0.5f * (c1.y + c2.y), 0.5f * (c2.x - c1.x));
+            const int ya = y0 + 2 * bi;  // rows outside the box are zero-filled by the Y pass
+            if (ya >= g.in.y0 && ya < y_hi) spec[spec_index(g, z, ya, k)] = A;
+            if (ya + 1 >= g.in.y0 && ya + 1 < y_hi) spec[spec_index(g, z, ya + 1, k)] = B;
+        }
     }
 }
 
@@ -113,17 +149,35 @@ __global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ sp
     const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp;
     const int total = (g.nT << g.lNB) << g.lTW;
-    for (int e = tid; e < total; e += nt) {
-        const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
-        const int k = (kt << g.lTW) + kk;
-        if (k >= g.Xc) continue;
-        const int ya = y0 + 2 * bi;  // rows outside the box were not produced by the Y pass
-        const float2 A = ya >= g.out.y0 && ya < y_hi ? spec[spec_index(g, z, ya, k)] : make_float2(0.f, 0.f);
-        const float2 B =
-            ya + 1 >= g.out.y0 && ya + 1 < y_hi ? spec[spec_index(g, z, ya + 1, k)] : make_float2(0.f, 0.f);
-        // C[k] = A + iB ; C[N-k] = conj(A) + i conj(B)
-        lds_ix[bi * N + ax.pos[k]] = make_float2(A.x - B.y, A.y + B.x);
-        if (k != 0 && 2 * k != N) lds_ix[bi * N + ax.pos[N - k]] = make_float2(A.x + B.y, B.x - A.y);
+    constexpr int kU = M3D_KU_XI;  // independent loads in flight per thread (see k_z_conv)
+    for (int e0 = tid; e0 < total; e0 += nt * kU) {
+        float2 Av[kU], Bv[kU];
+        int p1[kU], p2[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = min(e0 + u * nt, total - 1);
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int k = min((kt << g.lTW) + kk, g.Xc - 1);
+            p1[u] = ax.pos[k];
+            p2[u] = ax.pos[k == 0 ? 0 : N - k];
+            const int ya = y0 + 2 * bi;  // rows outside the box were not produced by the Y pass
+            const int yac = min(max(ya, g.out.y0), y_hi - 1), ybc = min(max(ya + 1, g.out.y0), y_hi - 1);
+            Av[u] = spec[spec_index(g, z, yac, k)];
+            Bv[u] = spec[spec_index(g, z, ybc, k)];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + u * nt;
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int k = (kt << g.lTW) + kk;
+            if (e >= total || k >= g.Xc) continue;
+            const int ya = y0 + 2 * bi;
+            const float2 A = ya >= g.out.y0 && ya < y_hi ? Av[u] : make_float2(0.f, 0.f);
+            const float2 B = ya + 1 >= g.out.y0 && ya + 1 < y_hi ? Bv[u] : make_float2(0.f, 0.f);
+            // C[k] = A + iB ; C[N-k] = conj(A) + i conj(B)
+            lds_ix[bi * N + p1[u]] = make_float2(A.x - B.y, A.y + B.x);
+            if (k != 0 && 2 * k != N) lds_ix[bi * N + p2[u]] = make_float2(A.x + B.y, B.x - A.y);
+        }
     }
     __syncthreads();
     lds_fft<true, RSET>(lds_ix, ax, 1, nb, N, tid, nt);
@@ -156,8 +210,17 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
     const int slo = INV ? bx.y0 * g.TW : 0, shi = INV ? (bx.y0 + bx.ny) * g.TW : n;  // store range
     if ((g.TW & 1) == 0) {  // 16-byte copies (tile bases are 16-B aligned when TW is even)
         float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
-        for (int i = tid; i < n / 2; i += nt)
-            l4[i] = (i >= lo / 2 && i < hi / 2) ? t4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int kU = M3D_KU_Y;  // independent 16-byte loads in flight per thread (see k_z_conv)
+        for (int i0 = tid; i0 < n / 2; i0 += nt * kU) {
+            float4 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) v[u] = t4[min(max(i0 + u * nt, lo / 2), hi / 2 - 1)];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int i = i0 + u * nt;
+                if (i < n / 2) l4[i] = (i >= lo / 2 && i < hi / 2) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     } else {
         for (int i = tid; i < n; i += nt) lds_y[i] = (i >= lo && i < hi) ? tile[i] : make_float2(0.f, 0.f);
     }
@@ -183,10 +246,31 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
     const int P = g.P;
     const int p = tid & (P - 1), z0 = tid >> g.lP, zstep = nt >> g.lP;  // nt is a multiple of P
     const bool live = p0 + p < g.plane;
-    float2 *col = spec + p0 + p;
+    // Loads are issued in batches of kU independent requests per thread (clamped addresses,
+    // select afterwards): a load -> LDS-store loop with a run-time trip count keeps one request
+    // in flight per wave, and the pass is then bound by HBM latency instead of bandwidth.
+    constexpr int kU = M3D_KU_Z;
+    const int64_t pc = live ? p0 + p : g.plane - 1;
+    float2 *col = spec + pc;
+    const int zin_hi = g.in.z0 + g.in.nz;
     for (int z = z0; z < g.Zp; z += zstep)  // planes outside the input's support are zero
-        lds_z[(z << g.lP) + p] = live && z >= g.in.z0 && z < g.in.z0 + g.in.nz ? col[(int64_t)z * g.plane]
-                                                                                : make_float2(0.f, 0.f);
+        if (z < g.in.z0 || z >= zin_hi) lds_z[(z << g.lP) + p] = make_float2(0.f, 0.f);
+    {
+        const int first = g.in.z0 + ((z0 - g.in.z0) % zstep + zstep) % zstep;  // first z >= in.z0, = z0 mod zstep
+        for (int zb = first; zb < zin_hi; zb += zstep * kU) {
+            float2 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int z = min(zb + u * zstep, zin_hi - 1);
+                v[u] = col[(int64_t)z * g.plane];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int z = zb + u * zstep;
+                if (z < zin_hi) lds_z[(z << g.lP) + p] = live ? v[u] : make_float2(0.f, 0.f);
+            }
+        }
+    }
     __syncthreads();
     lds_fft<false, RSET>(lds_z, az, P, P, 1, tid, nt);
     if (mode < 0) {
@@ -194,14 +278,24 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
             if (live) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
         return;
     }
-    const float2 *hcol = otf + p0 + p;
-    for (int z = z0; z < g.Zp; z += zstep) {
-        if (!live) continue;
-        float2 h = hcol[(int64_t)z * g.plane];
-        if (mode == 1) h.y = -h.y;
-        if (mode == 2) h = make_float2(h.x * h.x + h.y * h.y, 0.0f);
-        const float2 v = cmul(lds_z[(z << g.lP) + p], h);
-        lds_z[(z << g.lP) + p] = make_float2(v.x * scale, v.y * scale);
+    const float2 *hcol = otf + pc;
+    for (int zb = z0; zb < g.Zp; zb += zstep * kU) {
+        float2 hv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int z = min(zb + u * zstep, g.Zp - 1);
+            hv[u] = hcol[(int64_t)z * g.plane];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int z = zb + u * zstep;
+            if (z >= g.Zp) continue;
+            float2 h = hv[u];
+            if (mode == 1) h.y = -h.y;
+            if (mode == 2) h = make_float2(h.x * h.x + h.y * h.y, 0.0f);
+            const float2 v = cmul(lds_z[(z << g.lP) + p], h);
+            lds_z[(z << g.lP) + p] = make_float2(v.x * scale, v.y * scale);
+        }
     }
     __syncthreads();
     lds_fft<true, RSET>(lds_z, az, P, P, 1, tid, nt);
