@@ -48,6 +48,9 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
 // With an enabled `log`, six events bracket the five kernels (x fwd, y fwd, z conv, y inv, x inv).
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
-                 const ConvBox *out_box = nullptr);
+                 const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr);
+// `mirror_box` (exclusive with in_box): src is only valid inside the box and stands for its
+// symmetric extension to the whole volume (np.pad mode="symmetric", rlgc.py:203-271) - the
+// X pass gathers through the index map instead of reading a materialised pad region.
 
 }  // namespace m3d

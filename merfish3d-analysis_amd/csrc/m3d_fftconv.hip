@@ -23,6 +23,7 @@
 
 #include "m3d_common.h"
 #include "m3d_fft.h"
+#include "m3d_index.h"
 
 using namespace m3d;
 
@@ -61,6 +62,8 @@ struct ConvGeo {
     int lTW, lNB, lP;  // log2 of TW, RB/2, P (all powers of two)
     int64_t plane;
     m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
+    m3d::ConvBox mir;      // mirror != 0: the input is the symmetric extension of this box
+    int mirror;
 };
 
 __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, int k)
@@ -89,13 +92,18 @@ __global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src
     for (int bi = 0; bi < nb; ++bi) {
         const int ya = y0 + 2 * bi, yb = ya + 1;
         const bool va = ya >= g.in.y0 && ya < y_hi, vb = yb >= g.in.y0 && yb < y_hi;
-        const float *ra = src + ((int64_t)z * g.Yp + (va ? ya : g.in.y0)) * N;
-        const float *rbp = src + ((int64_t)z * g.Yp + (vb ? yb : g.in.y0)) * N;
+        // source rows: themselves, or their mirror images inside the box (symmetric extension)
+        const int zs = g.mirror ? sym_src(z, g.mir.z0, g.mir.nz) : z;
+        const int yas = g.mirror ? sym_src(min(ya, g.Yp - 1), g.mir.y0, g.mir.ny) : (va ? ya : g.in.y0);
+        const int ybs = g.mirror ? sym_src(min(yb, g.Yp - 1), g.mir.y0, g.mir.ny) : (vb ? yb : g.in.y0);
+        const float *ra = src + ((int64_t)zs * g.Yp + yas) * N;
+        const float *rbp = src + ((int64_t)zs * g.Yp + ybs) * N;
         for (int n0 = tid; n0 < N; n0 += nt * kUL) {
             float a[kUL], b[kUL];
 #pragma unroll
             for (int u = 0; u < kUL; ++u) {
-                const int n = min(n0 + u * nt, N - 1);
+                int n = min(n0 + u * nt, N - 1);
+                if (g.mirror) n = sym_src(n, g.mir.x0, g.mir.nx);
                 a[u] = ra[n];
                 b[u] = rbp[n];
             }
@@ -343,12 +351,15 @@ bool factor_23(int n, int *radix, int *nstages)
     return s <= kMaxStages;
 }
 
-ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d::ConvBox *out = nullptr)
+ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d::ConvBox *out = nullptr,
+               const m3d::ConvBox *mirror = nullptr)
 {
     ConvGeo g;
     const m3d::ConvBox full = {0, p->Zp, 0, p->Yp, 0, p->Xp};
     g.in = in ? *in : full;
     g.out = out ? *out : full;
+    g.mir = mirror ? *mirror : full;
+    g.mirror = mirror ? 1 : 0;
     g.Zp = p->Zp;
     g.Yp = p->Yp;
     g.Xp = p->Xp;
@@ -489,9 +500,10 @@ static int row_groups(const FftConvPlan *p, const m3d::ConvBox &b)
 }
 
 static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
-                             EventLog *log = nullptr, const ConvBox *in_box = nullptr)
+                             EventLog *log = nullptr, const ConvBox *in_box = nullptr,
+                             const ConvBox *mirror_box = nullptr)
 {
-    const ConvGeo g = geo_of(p, in_box);
+    const ConvGeo g = geo_of(p, in_box, nullptr, mirror_box);
     const int groups = row_groups(p, g.in);
     if (log && log->record()) return M3D_ERR_HIP;
     if (p->rset_x)
@@ -529,11 +541,13 @@ static bool box_ok(const FftConvPlan *p, const ConvBox *b)
 }
 
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
-                 float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box)
+                 float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
+                 const ConvBox *mirror_box)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (!box_ok(p, in_box) || !box_ok(p, out_box)) return M3D_ERR_INVALID_ARG;
-    int rc = launch_forward_xy(p, src, spec, st, log, in_box);
+    if (!box_ok(p, in_box) || !box_ok(p, out_box) || !box_ok(p, mirror_box) || (in_box && mirror_box))
+        return M3D_ERR_INVALID_ARG;
+    int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box);
     if (rc) return rc;
     if (log && log->record()) return M3D_ERR_HIP;
     const ConvGeo g = geo_of(p, in_box, out_box);

@@ -743,12 +743,16 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     // map): the engine skips the rows / planes that carry nothing (M3D_FFT_PRUNE=0 disables).
     const bool prune = !(getenv("M3D_FFT_PRUNE") && atoi(getenv("M3D_FFT_PRUNE")) == 0);
     const m3d::ConvBox core = {g.bz, g.Z, g.by, g.Y, g.bx, g.X};
-    enum { kFull = 0, kInCore = 1, kOutCore = 2 };
+    // The estimate itself is only ever written on the core; its symmetric boundary (rlgc.py:230-271)
+    // is gathered by the X pass (kMirrorIn) instead of being materialised by k_boundary.
+    enum { kFull = 0, kInCore = 1, kOutCore = 2, kMirrorIn = 4 };
+    const bool virtual_boundary = p->fc && prune;
     auto conv = [&](float *src, int mode, float *dst, int support = kFull) -> int {
         if (p->fc)  // six events per convolution: one in front of and one behind each kernel
             return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog,
-                                     prune && support == kInCore ? &core : nullptr,
-                                     prune && support == kOutCore ? &core : nullptr);
+                                     prune && (support & kInCore) ? &core : nullptr,
+                                     prune && (support & kOutCore) ? &core : nullptr,
+                                     prune && (support & kMirrorIn) ? &core : nullptr);
         int rc = stamp();
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
@@ -798,7 +802,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
 
     auto enqueue_forward = [&](int it) -> int {
-        int rc2 = conv(recon_cur, 0, hu, kOutCore);  // Hu, rlgc.py:624 (read on the core only)
+        int rc2 = conv(recon_cur, 0, hu, kOutCore | kMirrorIn);  // Hu, rlgc.py:624 (read on the core only)
         if (rc2) return rc2;
         const float *inj =
             (injected && it < n_injected) ? injected + (size_t)it * (size_t)g.N : nullptr;
@@ -823,7 +827,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         if ((rc2 = conv(hu, 2, w2, kOutCore))) return rc2;  // consensus_map, rlgc.py:677-679 (core only)
         hipLaunchKernelGGL(k_update, dim3(g_core), rb, 0, st, w2, recon_cur, w1, recon_prev, g,
                            up_part);
-        hipLaunchKernelGGL(k_boundary, dim3(g_pad), rb, 0, st, recon_prev, g);
+        if (!virtual_boundary) hipLaunchKernelGGL(k_boundary, dim3(g_pad), rb, 0, st, recon_prev, g);
         hipLaunchKernelGGL(k_update_finalize, dim3(1), dim3(kBlock), 0, st, up_part, g_core,
                            mm_part, g_pad, dstat);
         M3D_KERNEL_CHECK();
