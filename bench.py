@@ -148,6 +148,21 @@ def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
     }
 
 
+def pmc_traffic_per_conv(padded_shape):
+    """HBM bytes per fft_conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
+    WRITE_SIZE, profiles/r01_pmc_rlgc_traffic.json, made by scripts/pmc_summary.py) - only for
+    the FFT volume they were collected on, else None.  PMC collection needs its own profiler
+    passes, so this figure is measured offline, not inside this run."""
+    path = Path(__file__).resolve().parent / "profiles" / "r01_pmc_rlgc_traffic.json"
+    try:
+        d = json.loads(path.read_text())
+    except (OSError, ValueError):
+        return None
+    if abs(d.get("padded_volume_bytes", 0) - 4.0 * float(np.prod(padded_shape))) > 1:
+        return None
+    return round(float(d["fft_conv_hbm_bytes_per_launch"]), 1)
+
+
 def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tuple[float, float]:
     """(max elapsed over ranks, total RLGC iterations over ranks) - the bench contract's timing rule."""
     if world <= 1:
@@ -311,7 +326,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic_per_conv(padded),
                 "avg_ms": round(conv_ms, 3),
                 "launches": stats["conv_calls"],
                 "algorithmic_bytes_per_launch": RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full,
