@@ -15,8 +15,9 @@ to transcript table; the reference bounces every stage through host NumPy.  Devi
 * ``_global_normalization_vectors``  ``m3d_radix_hist`` exact order statistics, summed over
                        ranks with one RCCL all-reduce when tiles are sharded across GPUs
 
-Out of scope here: post-decode blank-fraction / LR filters,
-cell assignment, chromatic-affine estimation, napari display.
+The host-side tail of ``decode_all_tiles`` / ``optimize_filtering`` (blank-fraction filter, duplicate
+removal) lives in ``postdecode.py``.  Out of scope here: the LR
+filter, cell assignment from ROIs, chromatic-affine estimation, napari display.
 """
 
 from __future__ import annotations
@@ -1001,18 +1002,18 @@ class PixelDecoder:
         target_gross_misid_rate: float = 0.05,
         lr_fdr_target: float = 0.05,
     ) -> None:
-        """Decode every tile, sharded over GPUs (driver part of :4759-4844).
-
-        The downstream blank-fraction / LR filters, duplicate removal and cell assignment
-        (:4848-4870) are host-side post-processing outside this build's scope: the
-        per-tile tables are saved and gathered, nothing is filtered.
-        """
+        """Decode every tile, sharded over GPUs, then filter / de-duplicate / save the pooled
+        transcript table on the host (:4759-4870).  Under ``torch.distributed`` rank 0 does the
+        pooled post-processing after a barrier."""
         if self._num_gpus < 1:
             raise RuntimeError("No GPUs allocated.")
         if magnitude_threshold is None:
             magnitude_threshold = DEFAULT_DECODE_MAGNITUDE_THRESHOLD
         if minimum_pixels is None:
             minimum_pixels = self._default_minimum_pixels()
+        self._validate_filter_configuration(filter_method=filter_method,
+                                            target_gross_misid_rate=float(target_gross_misid_rate),
+                                            lr_fdr_target=float(lr_fdr_target))
         all_tiles = list(range(len(self._datastore.tile_ids)))
         shards, distributed = self._shard(all_tiles)
         if distributed or self._num_gpus == 1:
@@ -1038,8 +1039,155 @@ class PixelDecoder:
                       feature_predictor_threshold, normalization_method),
                 physical_gpu_id=gpu) for gpu, subset in enumerate(shards) if subset]
             _join_gpu_workers(procs, "Tile decoding")
-        if not distributed:
-            self._load_tile_decoding = True
-            self._load_all_barcodes()
-            if self._verbose >= 1:
-                print(f"Number of loaded barcodes: {len(self._df_barcodes_loaded)}")
+        if distributed:
+            import torch.distributed as dist
+
+            if dist.get_rank() != 0:
+                return
+        self._load_tile_decoding = True
+        self._load_all_barcodes()
+        if self._verbose >= 1:
+            print(f"Number of loaded barcodes: {len(self._df_barcodes_loaded)}")
+            print(f"Verbosity:  {self._verbose}")
+        self._apply_filter_method(filter_method=filter_method,
+                                  target_gross_misid_rate=float(target_gross_misid_rate),
+                                  lr_fdr_target=float(lr_fdr_target))
+        if not self._is_3D:
+            voxel = self._datastore.voxel_size_zyx_um
+            self._remove_duplicates_within_tile(
+                radius_xy=voxel[-1] if duplicate_radius_xy is None else float(duplicate_radius_xy),
+                radius_z=voxel[0] if duplicate_radius_z is None else float(duplicate_radius_z))
+        if len(all_tiles) > 1:
+            self._remove_duplicates_in_tile_overlap()
+        if assign_to_cells:
+            self._assign_cells()
+        self._save_barcodes()
+
+    # ------------------------------------------------------------------------------------
+    # post-decode filtering on the pooled table (host side)
+    # ------------------------------------------------------------------------------------
+    @staticmethod
+    def _validate_filter_configuration(filter_method, target_gross_misid_rate: float, lr_fdr_target: float) -> None:
+        """Each filter takes only its own target (:4872-4913)."""
+        if filter_method == "blank_fraction":
+            if lr_fdr_target != 0.05:
+                raise ValueError("lr_fdr_target only applies when filter_method='lr'. "
+                                 "Use target_gross_misid_rate with filter_method='blank_fraction'.")
+            return
+        if filter_method == "lr":
+            if target_gross_misid_rate != 0.05:
+                raise ValueError("target_gross_misid_rate only applies when filter_method='blank_fraction'. "
+                                 "Use lr_fdr_target with filter_method='lr'.")
+            return
+        raise ValueError("filter_method must be one of 'blank_fraction' or 'lr'.")
+
+    def _apply_filter_method(self, filter_method, target_gross_misid_rate: float, lr_fdr_target: float) -> None:
+        """:4915-4950."""
+        if self._verbose > 1:
+            print(f"apply filter_method={filter_method}")
+        if filter_method == "blank_fraction":
+            self._filter_all_barcodes_blank_fraction(target_gross_misid_rate=float(target_gross_misid_rate))
+            return
+        if filter_method == "lr":
+            self._filter_all_barcodes_LR(lr_fdr_target=float(lr_fdr_target))
+            return
+        raise ValueError("filter_method must be one of 'blank_fraction' or 'lr'.")
+
+    def _filter_all_barcodes_blank_fraction(self, target_gross_misid_rate: float = 0.05, intensity_bins=None,
+                                            voxel_number_bins=None, vector_distance_bins=None) -> None:
+        """Blank-fraction histogram filter in (magnitude, area, distance) space (:3386-3846)."""
+        from .postdecode import blank_fraction_filter
+
+        filtered, diagnostics = blank_fraction_filter(
+            self._df_barcodes_loaded, blank_count=self._blank_count, barcode_count=self._barcode_count,
+            target_gross_misid_rate=target_gross_misid_rate, intensity_bins=intensity_bins,
+            voxel_number_bins=voxel_number_bins, vector_distance_bins=vector_distance_bins)
+        if self._verbose > 1:
+            print("blank fraction filter diagnostics:")
+            for key, value in diagnostics.items():
+                if isinstance(value, (float, int, str, bool)):
+                    print(f"{key}: {value}")
+                else:
+                    print(f"{key}: {type(value)} with shape {getattr(value, 'shape', 'N/A')}")
+        self._blank_fraction_filter_results = diagnostics
+        self._df_filtered_barcodes = filtered
+        self._barcodes_filtered = True
+
+    def _filter_all_barcodes_LR(self, lr_fdr_target: float = 0.05) -> None:
+        raise NotImplementedError("the logistic-regression filter (:3907-4057) is not part of this build; "
+                                  "use filter_method='blank_fraction' (the reference's default)")
+
+    def _remove_duplicates_in_tile_overlap(self, radius: float = 0.75) -> None:
+        """:4137-4177."""
+        from .postdecode import remove_duplicates_in_tile_overlap
+
+        self._df_filtered_barcodes, dropped = remove_duplicates_in_tile_overlap(self._df_filtered_barcodes, radius)
+        if self._verbose > 1:
+            print("Average distance_min of dropped points (overlap): " + str(dropped.mean() if dropped.size else 0))
+            print("Dropped points: " + str(len(dropped)))
+
+    def _remove_duplicates_within_tile(self, radius_xy: float = 0.1, radius_z: float = 0.50) -> None:
+        """:4179-4363 - acts on the filtered table when there is one, else on the loaded table."""
+        from .postdecode import remove_duplicates_within_tile
+
+        filtered = getattr(self, "_df_filtered_barcodes", None) is not None
+        df = self._df_filtered_barcodes if filtered else getattr(self, "_df_barcodes_loaded", None)
+        if df is None or df.empty or len(df) < 2:
+            return
+        dmin = df["distance_min"].to_numpy(dtype=float)
+        out, dropped = remove_duplicates_within_tile(df, radius_xy=radius_xy, radius_z=radius_z)
+        if self._verbose > 1:
+            avg = float(dmin[dropped].mean()) if dropped else 0.0
+            print("Average distance_min of dropped points (within-tile, same gene, clusters): " + str(avg))
+            print("Dropped points: " + str(len(dropped)))
+        if filtered:
+            self._df_filtered_barcodes = out.copy()
+        else:
+            self._df_barcodes_loaded = out.copy()
+
+    def _assign_cells(self) -> None:
+        """Cell assignment from Cellpose ROIs needs roifile / shapely / rtree and a segmentation on
+        disk (:4076-4135); without them the reference prints and returns, and so does this."""
+        try:
+            from roifile import roiread  # noqa: F401
+        except ImportError as exc:
+            print(f"Failed to read ROIs: {exc}")
+            return
+        raise NotImplementedError("cell assignment from ImageJ ROIs is outside the hot path")
+
+    def optimize_filtering(self, assign_to_cells: bool = True, duplicate_radius_xy: float | None = None,
+                           duplicate_radius_z: float | None = None,
+                           filter_method: Literal["blank_fraction", "lr"] = "blank_fraction",
+                           target_gross_misid_rate: float = 0.05, lr_fdr_target: float = 0.05) -> None:
+        """Re-apply the downstream filter to previously decoded tiles (:4952-5030)."""
+        if self._verbose >= 1:
+            print("reprocess existing: load decoded transcripts")
+        self._load_tile_decoding = True
+        self._load_all_barcodes()
+        if self._verbose >= 1:
+            print(f"Number of loaded barcodes: {len(self._df_barcodes_loaded)}")
+        self._load_tile_decoding = False
+        self._validate_filter_configuration(filter_method=filter_method,
+                                            target_gross_misid_rate=float(target_gross_misid_rate),
+                                            lr_fdr_target=float(lr_fdr_target))
+        all_tiles = list(range(len(self._datastore.tile_ids)))
+        if self._verbose != 0:
+            self._verbose = 2
+        self._apply_filter_method(filter_method=filter_method, target_gross_misid_rate=float(target_gross_misid_rate),
+                                  lr_fdr_target=float(lr_fdr_target))
+        if len(all_tiles) or not self._is_3D:
+            if not self._is_3D:
+                voxel = self._datastore.voxel_size_zyx_um
+                self._remove_duplicates_within_tile(
+                    radius_xy=voxel[-1] if duplicate_radius_xy is None else float(duplicate_radius_xy),
+                    radius_z=voxel[0] if duplicate_radius_z is None else float(duplicate_radius_z))
+            else:
+                self._remove_duplicates_in_tile_overlap()
+        if self._verbose != 0:
+            self._verbose = 1
+        if assign_to_cells:
+            self._assign_cells()
+        self._save_barcodes()
+        if self._verbose >= 1:
+            print(f"Number of retained barcodes: {len(self._df_filtered_barcodes)}")
+

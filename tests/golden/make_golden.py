@@ -578,16 +578,117 @@ def make_sofima_jax_glue(sf):
     )
 
 
+def synthetic_barcode_table(rng, n=4000, n_tiles=3):
+    """Decoded-transcript table with the columns the post-decode stage reads; blanks are dimmer,
+    smaller and further from their codeword on average, with overlap so the filter has work."""
+    genes = np.array([f"gene{i:03d}" for i in range(130)] + [f"Blank-{i:02d}" for i in range(10)])
+    blank = rng.uniform(size=n) < 0.12
+    gid = np.where(blank, rng.integers(130, 140, size=n), rng.integers(0, 130, size=n))
+    mag = np.where(blank, rng.gamma(3.0, 0.25, size=n), rng.gamma(6.0, 0.3, size=n)).astype(np.float32)
+    area = np.where(blank, rng.integers(16, 30, size=n), rng.integers(16, 90, size=n)).astype(np.float64)
+    dist = np.where(blank, rng.uniform(0.25, 0.5176, size=n), rng.uniform(0.02, 0.5176, size=n) ** 1.3).astype(np.float32)
+    tile = rng.integers(0, n_tiles, size=n)
+    # tiles overlap in y; some transcripts are duplicated across tiles and across planes
+    zyx = np.stack([np.round(rng.uniform(0, 12, size=n)) * 0.31, rng.uniform(0, 60, size=n) + tile * 45.0,
+                    rng.uniform(0, 60, size=n)], axis=1)
+    dup = rng.choice(n, size=n // 10, replace=False)
+    src = rng.choice(np.setdiff1d(np.arange(n), dup), size=dup.size, replace=False)
+    zyx[dup] = zyx[src] + rng.normal(0, 0.03, size=(dup.size, 3)) + np.array([0.31, 0, 0]) * rng.integers(0, 2, size=(dup.size, 1))
+    gid[dup] = gid[src]
+    same_tile = rng.uniform(size=dup.size) < 0.5
+    tile[dup] = np.where(same_tile, tile[src], (tile[src] + 1) % n_tiles)
+    mag[7] = np.nan
+    return pd.DataFrame({"gene_id": genes[gid], "magnitude_mean": mag, "area": area, "distance_min": dist,
+                         "tile_idx": tile, "global_z": zyx[:, 0], "global_y": zyx[:, 1], "global_x": zyx[:, 2]}), genes
+
+
+def make_postdecode(pdm):
+    """_filter_all_barcodes_blank_fraction, _remove_duplicates_* (PixelDecoder.py:3386-3846, 4137-4363)
+    and calculate_F1_with_radius (cli/statphysbio_simulation/calculate_F1.py:19-200) on a synthetic table."""
+    import importlib
+
+    f1 = importlib.import_module("merfish3danalysis.cli.statphysbio_simulation.calculate_F1")
+    rng = np.random.default_rng(2024)
+    table, genes = synthetic_barcode_table(rng)
+    out = {"gene_names": genes, "gene_code": np.searchsorted(np.sort(genes), table["gene_id"].to_numpy()),
+           "gene_sorted": np.sort(genes)}
+    for c in table.columns[1:]:
+        out[c] = table[c].to_numpy()
+
+    def run_filter(tag, df, **kw):
+        dec = pdm.PixelDecoder.__new__(pdm.PixelDecoder)
+        dec._df_barcodes_loaded = df.copy()
+        dec._blank_count, dec._barcode_count, dec._verbose = 10, 140, 0
+        dec._filter_all_barcodes_blank_fraction(**kw)
+        d = dec._blank_fraction_filter_results
+        kept = dec._df_filtered_barcodes
+        out[f"{tag}_kept_rows"] = kept.index.to_numpy()
+        out[f"{tag}_kept_fraction"] = kept["blank_fraction"].to_numpy()
+        out[f"{tag}_kept_bin"] = kept["blank_fraction_bin"].to_numpy()
+        for k in ("chosen_threshold", "achieved_gross_misid_rate", "target_reached", "all_histogram", "blank_histogram",
+                  "blank_fraction_histogram", "intensity_bins", "voxel_number_bins", "vector_distance_bins"):
+            out[f"{tag}_{k}"] = np.asarray(d[k])
+        out[f"{tag}_sweep"] = d["threshold_sweep"].to_numpy(dtype=float)
+        out[f"{tag}_reason"] = np.asarray(d.get("reason", ""))
+        return kept
+
+    kept = run_filter("auto", table, target_gross_misid_rate=0.05)
+    run_filter("strict", table, target_gross_misid_rate=1e-4)
+    run_filter("explicit", table, target_gross_misid_rate=0.1, intensity_bins=[0.0, 0.8, 1.5, 2.5, 10.0],
+               voxel_number_bins=[15.5, 20.5, 40.5, 100.5], vector_distance_bins=np.linspace(0.0, 0.52, 6))
+    few = table.iloc[:40].copy()
+    few["area"] = 16.0 + (np.arange(40) % 4)
+    out["few_area"] = few["area"].to_numpy()
+    run_filter("few", few, target_gross_misid_rate=0.05)
+    noblank = table[~table["gene_id"].str.startswith("Blank")].iloc[:50]
+    out["noblank_rows"] = noblank.index.to_numpy()
+    run_filter("noblank", noblank, target_gross_misid_rate=0.05)
+
+    # duplicate removal on the auto-filtered table: 2-D style within-tile collapse, then tile overlap
+    dec = pdm.PixelDecoder.__new__(pdm.PixelDecoder)
+    dec._verbose = 0
+    dec._df_filtered_barcodes = kept.copy()
+    dec._df_filtered_barcodes["row_id"] = kept.index.to_numpy()
+    dec._remove_duplicates_within_tile(radius_xy=0.098, radius_z=0.31)
+    out["within_rows"] = dec._df_filtered_barcodes["row_id"].to_numpy()
+    dec._remove_duplicates_in_tile_overlap(radius=0.75)
+    out["overlap_rows"] = dec._df_filtered_barcodes["row_id"].to_numpy()
+
+    # F1 scorer: ground truth = a jittered subset of the kept transcripts + unmatched extras
+    final = dec._df_filtered_barcodes
+    q = final[["global_z", "global_y", "global_x"]].to_numpy()
+    qg = final["gene_id"].to_numpy()
+    pick = rng.uniform(size=len(final)) < 0.8
+    gt = q[pick] + rng.normal(0, 0.25, size=(int(pick.sum()), 3))
+    gtg = qg[pick].copy()
+    swap = rng.uniform(size=gtg.size) < 0.05
+    gtg[swap] = genes[rng.integers(0, 130, size=int(swap.sum()))]
+    extra = rng.uniform((0, 0, 0), (4, 150, 60), size=(200, 3))
+    gt = np.concatenate([gt, extra])
+    gtg = np.concatenate([gtg, genes[rng.integers(0, 130, size=200)]])
+    out["f1_gt"], out["f1_gt_gene"] = gt, gtg.astype(str)
+    for tag, radius in (("r1", 1.0), ("r03", 0.3)):
+        res, tp, fp, fn = f1.calculate_F1_with_radius(q, qg, gt, gtg, radius)
+        out[f"f1_{tag}_metrics"] = np.asarray([res["F1 Score"], res["Precision"], res["Recall"], res["True Positives"],
+                                               res["False Positives"], res["False Negatives"]], dtype=float)
+        out[f"f1_{tag}_tp"], out[f"f1_{tag}_fp"], out[f"f1_{tag}_fn"] = tp, fp, fn
+    np.savez_compressed(HERE / "postdecode.npz", **out)
+
+
 def main():
     rl, mv, dw, sf, pdm = import_reference()
     if "--sofima-jax-only" in sys.argv:
         make_sofima_jax_glue(sf)
+        return
+    if "--postdecode-only" in sys.argv:
+        make_postdecode(pdm)
         return
     make_rlgc(rl)
     make_decode(pdm)
     make_normalization(pdm)
     make_registration(mv, dw, sf)
     make_sofima_jax_glue(sf)
+    make_postdecode(pdm)
     print("golden fixtures written to", HERE)
 
 

@@ -1,6 +1,7 @@
 """GPU parity: connected components + region statistics + the whole decode_one_tile."""
 
 import numpy as np
+import pandas as pd
 import pytest
 import torch
 
@@ -144,3 +145,37 @@ def test_decode_one_tile_2d_mode_and_z_range(golden):
     with pytest.raises(ValueError):
         PD.PixelDecoder(store, merfish_bits=16, verbose=0, z_range=(1, 2), decode_mode="3d").decode_one_tile(
             lowpass_sigma=None, normalization_method="none")
+
+
+def test_decode_all_tiles_filters_and_saves_the_pooled_table(golden):
+    """decode_all_tiles end to end on two overlapping copies of one tile: per-tile tables saved,
+    pooled table blank-fraction filtered, cross-tile duplicates removed (PixelDecoder.py:4759-4870)."""
+    from oracle import decode_ref  # noqa: F401  (helpers import)
+    PD = pkg("PixelDecoder")
+    post = pkg("postdecode")
+    g = golden("decode_pixels_16")
+    genes = list(g["gene_ids"])
+    cb = codebook_frame(g["codebook_bits"], genes)
+    store = store_from_stack([g["lowpass"], g["lowpass"]], cb)     # two tiles imaging the same field
+    store.save_decode_normalization_vectors(None, "global", g["normalization"], g["background"])
+    dec = PD.PixelDecoder(store, merfish_bits=g["codebook_bits"].shape[1], verbose=0)
+    dec.decode_all_tiles(assign_to_cells=True, lowpass_sigma=None, magnitude_threshold=tuple(g["magnitude_threshold"]),
+                         minimum_pixels=3, normalization_method="global", target_gross_misid_rate=0.05)
+    per_tile = [store.load_local_decoded_spots(t) for t in store.tile_ids]
+    assert len(per_tile[0]) > 20 and len(per_tile[0]) == len(per_tile[1])
+    pooled = pd.concat(per_tile)
+    pooled = pooled[pooled["gene_id"].notna()]
+    want, _ = post.blank_fraction_filter(pooled, blank_count=dec._blank_count, barcode_count=dec._barcode_count,
+                                         target_gross_misid_rate=0.05)
+    want, _ = post.remove_duplicates_in_tile_overlap(want)
+    saved = store.load_global_filtered_decoded_spots()
+    assert list(saved.columns) == list(want.columns) and "cell_id" in saved.columns
+    pd.testing.assert_frame_equal(saved.reset_index(drop=True), want.reset_index(drop=True))
+    # identical tiles at identical stage positions: every transcript had a cross-tile twin, one survives
+    assert 0 < len(saved) <= len(per_tile[0])
+    assert dec._barcodes_filtered and (saved["cell_id"] == -1).all()
+    # optimize_filtering re-runs the host stage from the saved per-tile tables
+    dec2 = PD.PixelDecoder(store, merfish_bits=g["codebook_bits"].shape[1], verbose=0)
+    dec2.optimize_filtering(assign_to_cells=False, target_gross_misid_rate=0.05)
+    pd.testing.assert_frame_equal(store.load_global_filtered_decoded_spots().reset_index(drop=True),
+                                  want.reset_index(drop=True))
