@@ -1,0 +1,130 @@
+"""GPU, BASELINE.json configs[1] sizes (64 x 2048 x 2048 tile, 22 bits, 140 codewords): the oracle
+cannot run here in seconds, so parity is carried by size-independent properties -
+determinism, pruned == unpruned convolutions, tiling invariance of per-voxel stages, and exact
+agreement with the oracle on a random sample of voxels gathered from the full-size result."""
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import decode_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SHAPE = (64, 2048, 2048)
+
+
+def _hw4_codebook(n_bits=22, n_codes=140, seed=0):
+    """Constant-weight-4 codewords with pairwise Hamming distance >= 4 (greedy)."""
+    import itertools
+
+    rng = np.random.default_rng(seed)
+    combos = list(itertools.combinations(range(n_bits), 4))
+    rng.shuffle(combos)
+    chosen = []
+    for c in combos:
+        s = set(c)
+        if all(len(s & set(o)) <= 2 for o in chosen):
+            chosen.append(c)
+            if len(chosen) == n_codes:
+                break
+    bits = np.zeros((len(chosen), n_bits), dtype=np.int64)
+    for i, c in enumerate(chosen):
+        bits[i, list(c)] = 1
+    return bits
+
+
+def test_rlgc_full_size_is_deterministic_and_pruning_invariant(monkeypatch):
+    rl = pkg("utils.rlgc")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    img = torch.poisson(torch.rand(SHAPE, device=DEV, generator=g) * 300 + 80, generator=g).to(torch.uint16)
+    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (64, 51, 51)], indexing="ij")
+    psf = torch.exp(-0.5 * ((zz / 3.0) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2)).float()
+    out1, info1 = rl.rlgc_device(img, psf, rng_seed=7, max_iterations=3)
+    first = out1.clone()
+    out2, info2 = rl.rlgc_device(img, psf, rng_seed=7, max_iterations=3)
+    assert info1.padded_shape == (128, 2187, 2187) and info1.fused_engine and info1.iterations == 3
+    assert torch.equal(first, out2)                                     # same seed -> same bits
+    assert list(info1.kld_split1[:3]) == list(info2.kld_split1[:3])
+    assert torch.isfinite(first).all() and float(first.min()) >= 0.0
+    # the update multiplies by HT1 + HT2 of two half-flux splits (rlgc.py:674-682): the estimate carries
+    # twice the data's flux, conserved by every Richardson-Lucy step
+    assert abs(float(first.mean()) / float(img.float().mean()) - 2.0) < 0.02
+    out3, info3 = rl.rlgc_device(img, psf, rng_seed=8, max_iterations=3)
+    assert not torch.equal(first, out3)                                 # the seed matters
+    monkeypatch.setenv("M3D_FFT_PRUNE", "0")
+    full, finfo = rl.rlgc_device(img, psf, rng_seed=7, max_iterations=3)
+    assert finfo.iterations == 3
+    rel = float((full - first).abs().max() / first.abs().max())
+    assert rel < 2e-5, rel
+    np.testing.assert_allclose(finfo.kld_split1[:3], info1.kld_split1[:3], rtol=1e-5)
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+
+
+def test_decode_full_size_is_tiling_invariant_and_matches_oracle_on_samples():
+    kernels = pkg("kernels")
+    bits = _hw4_codebook()
+    assert bits.shape == (140, 22)
+    matrix = decode_ref.normalize_codebook(bits.astype(np.float32))
+    thr = decode_ref.codebook_thresholds(4)[0]
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B = 22
+    stack = torch.empty((B,) + SHAPE, dtype=torch.float32, device=DEV)
+    code_of = torch.randint(0, 140, SHAPE, device=DEV, generator=g)
+    lit = torch.rand(SHAPE, device=DEV, generator=g) < 0.02            # 2 % of voxels carry a codeword
+    cb = torch.from_numpy(bits).to(DEV)
+    for b in range(B):
+        on = cb[:, b][code_of].bool() & lit
+        stack[b] = torch.rand(SHAPE, device=DEV, generator=g) * 0.4 + on * (1.5 + torch.rand(SHAPE, device=DEV, generator=g))
+    del code_of, lit
+    bk = torch.full((B,), 0.2, device=DEV)
+    nm = torch.linspace(0.8, 1.3, B, device=DEV)
+    kw = dict(magnitude_threshold=(1.5, 10.0), background=bk, normalization=nm, excluded_indices=(3, 77))
+    dec, mag, dist, sc = kernels.decode_pixels(stack, torch.from_numpy(matrix), float(thr), **kw)
+    torch.cuda.synchronize()
+    called = int((dec >= 0).sum())
+    assert 0.005 * dec.numel() < called < 0.03 * dec.numel()
+    assert not bool(((dec == 3) | (dec == 77)).any())                   # excluded codewords are never called
+    # tiling invariance: the stage is per voxel
+    z0 = 17
+    part = kernels.decode_pixels(stack[:, z0:z0 + 5].contiguous(), torch.from_numpy(matrix), float(thr), **kw)
+    for whole, piece in zip((dec, mag, dist), part[:3]):
+        assert torch.equal(whole[z0:z0 + 5], piece)
+    assert torch.equal(sc[:, z0:z0 + 5], part[3])
+    # exact agreement with the oracle on 20 000 sampled voxels (biased towards called ones)
+    idx_called = torch.nonzero(dec.view(-1) >= 0).view(-1)
+    pick = torch.cat([idx_called[torch.randint(0, idx_called.numel(), (10000,), device=DEV, generator=g)],
+                      torch.randint(0, dec.numel(), (10000,), device=DEV, generator=g)])
+    traces = stack.view(B, -1)[:, pick].cpu().numpy().reshape(B, 1, 1, -1)
+    rdec, rmag, rdist, rsc = decode_ref.decode_pixels(traces, matrix, float(thr), arith="device",
+                                                      magnitude_threshold=(1.5, 10.0), background=bk.cpu().numpy(),
+                                                      normalization=nm.cpu().numpy(), excluded_indices=(3, 77))
+    np.testing.assert_array_equal(dec.view(-1)[pick].cpu().numpy(), rdec.reshape(-1))
+    np.testing.assert_array_equal(mag.view(-1)[pick].cpu().numpy().view(np.uint16), rmag.reshape(-1).view(np.uint16))
+    np.testing.assert_array_equal(dist.view(-1)[pick].cpu().numpy().view(np.uint16), rdist.reshape(-1).view(np.uint16))
+    np.testing.assert_array_equal(sc.view(B, -1)[:, pick].cpu().numpy().view(np.uint16),
+                                  rsc.reshape(B, -1).view(np.uint16))
+    # connected components at full size: every called voxel belongs to exactly one component, roots are
+    # each component's first voxel in raster order and carry the component's codeword, and the 64-plane
+    # result restricted to components that live entirely in z < 8 equals an 8-plane run
+    table = kernels.connected_component_table(dec, sc, mag, dist)
+    area = table["sums"][:, 0]
+    assert int(area.sum()) == called and (area >= 1).all()
+    roots = table["root"].astype(np.int64)
+    assert (np.diff(roots) > 0).all()
+    np.testing.assert_array_equal(dec.view(-1)[torch.from_numpy(roots).to(DEV)].cpu().numpy(), table["code"])
+    labels = table["labels"]
+    assert int((labels.view(-1)[torch.from_numpy(roots).to(DEV)] >= 0).all())
+    slab = kernels.connected_component_table(dec[:8].contiguous(), sc[:, :8].contiguous(), mag[:8].contiguous(),
+                                             dist[:8].contiguous())
+    plane = SHAPE[1] * SHAPE[2]
+    touches_cut = set(torch.unique(slab["labels"][7][dec[7] >= 0]).cpu().numpy().tolist())
+    # components of the slab run that do not reach its last plane are complete components of the full run
+    keep = np.array([r not in touches_cut for r in slab["root"]])
+    full_small = roots < 8 * plane
+    full_rows = {int(r): i for i, r in enumerate(roots[full_small])}
+    idx = np.array([full_rows[int(r)] for r in slab["root"][keep]])
+    np.testing.assert_array_equal(table["sums"][full_small][idx], slab["sums"][keep])
+    np.testing.assert_array_equal(table["code"][full_small][idx], slab["code"][keep])
+    assert keep.sum() > 1000
