@@ -42,6 +42,7 @@ WORKLOADS = {
     "config1": ((16, 256, 256), 16, (16, 51, 51), 1_200),
 }
 RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL = 20.0  # 2 FFTs x 8 B + OTF read 4 B
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
@@ -349,6 +350,31 @@ def main() -> None:
                  "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
                  "bytes_per_voxel": round(bpv, 2)}
                 for nme, ms, bpv in zip(names, stats["kernel_ms"], moved)]
+        # the one dense contraction of the path, outside the timed region: the fused decode kernel
+        # (exact-f32 MFMA distance step) on this tile's low-passed bit stack, HIP events on the
+        # stream it is launched on
+        decoder._tile_idx = 0
+        decoder._load_global_normalization_vectors(gpu_id=local_rank)
+        decoder._load_bit_data(gpu_id=local_rank)
+        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=local_rank)
+        decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=local_rank)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 3
+        ev[0].record()
+        for _ in range(reps):
+            decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=local_rank)
+        ev[1].record()
+        torch.cuda.synchronize(device)
+        dec_ms = ev[0].elapsed_time(ev[1]) / reps
+        decoder._cleanup()
+        flop = 2.0 * n_bits * len(bits_matrix) * n_tile
+        out["roofline_decode"] = {
+            "kernel": "k_decode (scale, clip, L2 norm, codeword distances on v_mfma_f32_32x32x2_f32, argmin, thresholds)",
+            "bound": "mfma", "achieved": round(flop / (dec_ms * 1e-3) / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(flop / (dec_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "avg_ms": round(dec_ms, 3), "flop_per_launch": flop,
+            "hbm_gbs": round((4.0 * n_bits + 6.0 + 2.0 * n_bits) * n_tile / (dec_ms * 1e-3) / 1e9, 1),
+        }
         if world == 1 and not args.no_cpu_baseline:
             iters_per_bit = total_iters / max(args.steps * n_bits, 1)
             out["cpu_baseline"] = cpu_baseline(readouts[0], psf, bits_matrix, shape, n_bits, iters_per_bit)

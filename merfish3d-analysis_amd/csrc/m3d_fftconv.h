@@ -43,12 +43,43 @@ void fftconv_destroy(FftConvPlan *p);
 int64_t fftconv_spectrum_elems(const FftConvPlan *p);
 // otf <- forward transform of the padded, centred PSF volume
 int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf, void *stream);
+// Optional fused tail of the X inverse pass: the convolution result is combined with other
+// volumes in the store loop instead of being written to dst and read back by the next kernel.
+//   kConsensus (rlgc.py:661-678, full volume): HT1 = a / b, HT2 = result / b;
+//       o1 <- (HT1 - 1)(HT2 - 1); o2 <- HT1 + HT2 on the core (o2 may alias a);
+//       red[0] / red[1] <- min / max of HT1 + HT2 as ordered keys (float_key below)
+//   kUpdate (filter_update rlgc.py:23-31, :682-694, core only): c = result, old = a;
+//       o1 <- c < 0 ? old : old * b; red64[0] += (c >= 0); red[2] <- max o1 (key); red[3] <- max |o1 - old| (bits)
+struct ConvEpilogue {
+    enum Kind { kNone = 0, kConsensus = 1, kUpdate = 2 };
+    int kind;
+    const float *a, *b;
+    float *o1, *o2;
+    unsigned int *red;  // 16-byte aligned, >= 4 words
+    ConvBox core;
+};
+// order-preserving map float -> uint32 (atomicMin / atomicMax on floats of either sign)
+__host__ __device__ inline unsigned int float_key(float f)
+{
+    unsigned int b;
+    __builtin_memcpy(&b, &f, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float key_float(unsigned int k)
+{
+    const unsigned int b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    float f;
+    __builtin_memcpy(&f, &b, 4);
+    return f;
+}
+
 // dst <- irfftn(rfftn(src) * H) with H = otf (mode 0), conj(otf) (1), |otf|^2 (2);
 // `spec` is a scratch spectrum.  src may equal dst.
 // With an enabled `log`, six events bracket the five kernels (x fwd, y fwd, z conv, y inv, x inv).
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
-                 const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr);
+                 const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr,
+                 const ConvEpilogue *epilogue = nullptr);
 // `mirror_box` (exclusive with in_box): src is only valid inside the box and stands for its
 // symmetric extension to the whole volume (np.pad mode="symmetric", rlgc.py:203-271) - the
 // X pass gathers through the index map instead of reading a materialised pad region.

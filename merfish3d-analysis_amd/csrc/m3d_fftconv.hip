@@ -145,10 +145,94 @@ __global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src
     }
 }
 
+// ---------------------------------------------------------------- fused tails of the X inverse pass
+// Exact elementwise arithmetic (this file is otherwise built with -ffp-contract=fast): the same
+// operation order as k_consensus_in / k_update of m3d_rlgc.hip, whose results these must equal.
+template <int EPI>
+__device__ __forceinline__ void x_inverse_epilogue(const float2 *lds, const ConvGeo &g, const m3d::ConvEpilogue &ep,
+                                                   int z, int y0, int nb, int N, int y_hi, int x_hi, int tid, int nt)
+{
+#pragma clang fp contract(off)
+    __shared__ float smf[4];
+    __shared__ unsigned long long smu[4];
+    constexpr int kU = 3;
+    float mn = INFINITY, mx = -INFINITY, dmax = 0.0f;
+    unsigned long long updated = 0;
+    const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
+    for (int bi = 0; bi < nb; ++bi) {
+        const int yr[2] = {y0 + 2 * bi, y0 + 2 * bi + 1};
+        bool valid[2];
+        int64_t row[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            valid[r] = yr[r] >= g.out.y0 && yr[r] < y_hi;
+            row[r] = ((int64_t)z * g.Yp + (valid[r] ? yr[r] : g.out.y0)) * N;
+        }
+        for (int n0 = g.out.x0 + tid; n0 < x_hi; n0 += nt * kU) {
+            float av[2][kU], bv[2][kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int n = min(n0 + u * nt, x_hi - 1);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    av[r][u] = ep.a[row[r] + n];
+                    bv[r][u] = ep.b[row[r] + n];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int n = n0 + u * nt;
+                if (n >= x_hi) continue;
+                const float2 v = lds[bi * N + n];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (!valid[r]) continue;
+                    const float c = r ? v.y : v.x;
+                    if constexpr (EPI == m3d::ConvEpilogue::kConsensus) {
+                        const float un = bv[r][u];
+                        const float h1 = av[r][u] / un, h2 = c / un;
+                        ep.o1[row[r] + n] = (h1 - 1.0f) * (h2 - 1.0f);
+                        const float hs = h1 + h2;
+                        mn = fminf(mn, hs);
+                        mx = fmaxf(mx, hs);
+                        const bool core = z_core && yr[r] >= ep.core.y0 && yr[r] < ep.core.y0 + ep.core.ny &&
+                                          n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx;
+                        if (core) ep.o2[row[r] + n] = hs;
+                    } else {
+                        const float old = av[r][u];
+                        const float nw = c < 0.0f ? old : old * bv[r][u];
+                        ep.o1[row[r] + n] = nw;
+                        updated += (c >= 0.0f) ? 1ull : 0ull;
+                        mx = fmaxf(mx, nw);
+                        dmax = fmaxf(dmax, fabsf(nw - old));
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == m3d::ConvEpilogue::kConsensus) {
+        mn = block_min(mn, smf);
+        mx = block_max(mx, smf);
+        if (tid == 0) {
+            atomicMin(&ep.red[0], m3d::float_key(mn));
+            atomicMax(&ep.red[1], m3d::float_key(mx));
+        }
+    } else {
+        updated = block_sum(updated, smu);
+        mx = block_max(mx, smf);
+        dmax = block_max(dmax, smf);
+        if (tid == 0) {
+            if (updated) atomicAdd((unsigned long long *)ep.red, updated);
+            atomicMax(&ep.red[2], m3d::float_key(mx));
+            atomicMax(&ep.red[3], __float_as_uint(dmax));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- X inverse (C2R)
-template <int RSET>
+template <int RSET, int EPI>
 __global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__ dst, ConvGeo g,
-                            AxisPlan ax)
+                            AxisPlan ax, m3d::ConvEpilogue ep)
 {
     extern __shared__ float2 lds_ix[];
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -189,16 +273,20 @@ __global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ sp
     }
     __syncthreads();
     lds_fft<true, RSET>(lds_ix, ax, 1, nb, N, tid, nt);
-    for (int bi = 0; bi < nb; ++bi) {
-        const int ya = y0 + 2 * bi, yb = ya + 1;
-        float *ra = dst + ((int64_t)z * g.Yp + ya) * N;
-        float *rbp = ra + N;
-        const bool va = ya >= g.out.y0 && ya < y_hi, vb = yb >= g.out.y0 && yb < y_hi;
-        for (int n = g.out.x0 + tid; n < x_hi; n += nt) {
-            const float2 v = lds_ix[bi * N + n];
-            if (va) ra[n] = v.x;
-            if (vb) rbp[n] = v.y;
+    if constexpr (EPI == m3d::ConvEpilogue::kNone) {
+        for (int bi = 0; bi < nb; ++bi) {
+            const int ya = y0 + 2 * bi, yb = ya + 1;
+            float *ra = dst + ((int64_t)z * g.Yp + ya) * N;
+            float *rbp = ra + N;
+            const bool va = ya >= g.out.y0 && ya < y_hi, vb = yb >= g.out.y0 && yb < y_hi;
+            for (int n = g.out.x0 + tid; n < x_hi; n += nt) {
+                const float2 v = lds_ix[bi * N + n];
+                if (va) ra[n] = v.x;
+                if (vb) rbp[n] = v.y;
+            }
         }
+    } else {
+        x_inverse_epilogue<EPI>(lds_ix, g, ep, z, y0, nb, N, y_hi, x_hi, tid, nt);
     }
 }
 
@@ -472,8 +560,12 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     (void)hipFuncSetAttribute((const void *)k_x_forward<0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_forward<1>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<0>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<1>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 0>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 0>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 1>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 1>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 2>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 2>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
@@ -542,7 +634,7 @@ static bool box_ok(const FftConvPlan *p, const ConvBox *b)
 
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
-                 const ConvBox *mirror_box)
+                 const ConvBox *mirror_box, const ConvEpilogue *epilogue)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!box_ok(p, in_box) || !box_ok(p, out_box) || !box_ok(p, mirror_box) || (in_box && mirror_box))
@@ -564,10 +656,24 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
         hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     if (log && log->record()) return M3D_ERR_HIP;
     const int groups = row_groups(p, g.out);
-    if (p->rset_x)
-        hipLaunchKernelGGL(k_x_inverse<1>, dim3((unsigned)(g.out.nz * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
-    else
-        hipLaunchKernelGGL(k_x_inverse<0>, dim3((unsigned)(g.out.nz * groups)), dim3(256), p->lds_x, st, spec, dst, g, p->ax);
+    const dim3 xg((unsigned)(g.out.nz * groups)), xb(256);
+    ConvEpilogue ep = {};
+    if (epilogue) ep = *epilogue;
+    if (ep.kind != ConvEpilogue::kNone && (!ep.a || !ep.b || !ep.o1 || !ep.red ||
+                                           (ep.kind == ConvEpilogue::kConsensus && !ep.o2)))
+        return M3D_ERR_INVALID_ARG;
+#define M3D_LAUNCH_XI(RS, EP) \
+    hipLaunchKernelGGL((k_x_inverse<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
+    if (p->rset_x) {
+        if (ep.kind == ConvEpilogue::kConsensus) M3D_LAUNCH_XI(1, 1);
+        else if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XI(1, 2);
+        else M3D_LAUNCH_XI(1, 0);
+    } else {
+        if (ep.kind == ConvEpilogue::kConsensus) M3D_LAUNCH_XI(0, 1);
+        else if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XI(0, 2);
+        else M3D_LAUNCH_XI(0, 0);
+    }
+#undef M3D_LAUNCH_XI
     if (log && log->record()) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;

@@ -394,6 +394,33 @@ __global__ void k_update_finalize(const UpdPartial *__restrict__ up, int n_up,
     }
 }
 
+// Fused-tail variant (ConvEpilogue in m3d_fftconv.h): the X inverse passes of the last two
+// convolutions leave min / max / count as atomics; this reads them into the status record and
+// re-arms them for the next iteration.
+__device__ __forceinline__ void arm_fused_reductions(unsigned int *cons, unsigned int *upd)
+{
+    cons[0] = m3d::float_key(INFINITY);   // min HT1 + HT2
+    cons[1] = m3d::float_key(-INFINITY);  // max HT1 + HT2
+    upd[0] = 0u;                          // updated voxels (low / high word)
+    upd[1] = 0u;
+    upd[2] = m3d::float_key(-INFINITY);   // max of the new estimate
+    upd[3] = 0u;                          // max |delta| (non-negative: raw bits order like floats)
+}
+__global__ void k_arm_fused_reductions(unsigned int *cons, unsigned int *upd)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) arm_fused_reductions(cons, upd);
+}
+__global__ void k_fused_finalize(unsigned int *cons, unsigned int *upd, Status *st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st->updated = *(const unsigned long long *)upd;
+    st->recon_max = m3d::key_float(upd[2]);
+    st->max_abs_delta = __uint_as_float(upd[3]);
+    st->ht_min = m3d::key_float(cons[0]);
+    st->ht_max = m3d::key_float(cons[1]);
+    arm_fused_reductions(cons, upd);
+}
+
 // enforce_symmetric_boundary (rlgc.py:230-271): z, then y, then x passes compose to
 // recon[z,y,x] = recon[s(z), s(y), s(x)] with every source inside the core.
 __global__ void k_boundary(float *__restrict__ recon, Geo g)
@@ -747,12 +774,17 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     // is gathered by the X pass (kMirrorIn) instead of being materialised by k_boundary.
     enum { kFull = 0, kInCore = 1, kOutCore = 2, kMirrorIn = 4 };
     const bool virtual_boundary = p->fc && prune;
-    auto conv = [&](float *src, int mode, float *dst, int support = kFull) -> int {
+    // ... and the elementwise kernels that follow the second ratio convolution and the consensus
+    // convolution run inside those convolutions' X inverse store loops (ConvEpilogue).
+    const bool fused_tail = p->fc && prune;
+    unsigned int *cons_red = (unsigned int *)mm_part, *upd_red = (unsigned int *)up_part;
+    auto conv = [&](float *src, int mode, float *dst, int support = kFull,
+                    const m3d::ConvEpilogue *epi = nullptr) -> int {
         if (p->fc)  // six events per convolution: one in front of and one behind each kernel
             return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog,
                                      prune && (support & kInCore) ? &core : nullptr,
                                      prune && (support & kOutCore) ? &core : nullptr,
-                                     prune && (support & kMirrorIn) ? &core : nullptr);
+                                     prune && (support & kMirrorIn) ? &core : nullptr, epi);
         int rc = stamp();
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
@@ -797,6 +829,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     hipLaunchKernelGGL(k_fill_from, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, recon_cur,
                        &dstat->mean, g.Np);
     M3D_KERNEL_CHECK();
+    if (fused_tail) hipLaunchKernelGGL(k_arm_fused_reductions, dim3(1), dim3(64), 0, st, cons_red, upd_red);
     // ratio volumes: pad region stays zero for the whole run (only the core is rewritten)
     M3D_HIP_CHECK(hipMemsetAsync(r1, 0, sizeof(float) * (size_t)g.Np, st));
     M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
@@ -821,6 +854,18 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     auto enqueue_update = [&]() -> int {
         int rc2;
         if ((rc2 = conv(r1, 1, w1, kInCore))) return rc2;  // HTratio1 * update_norm, rlgc.py:654-662
+        if (fused_tail) {
+            // HTratio2 (rlgc.py:664-672) never reaches memory: its X inverse pass writes the consensus
+            // input and HT1 + HT2 directly; likewise the consensus map feeds the gated update in place
+            const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, w1, un, hu, w1, cons_red, core};
+            if ((rc2 = conv(r2, 1, w2, kInCore, &e1))) return rc2;
+            const m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr,
+                                          upd_red, core};
+            if ((rc2 = conv(hu, 2, w2, kOutCore, &e2))) return rc2;
+            hipLaunchKernelGGL(k_fused_finalize, dim3(1), dim3(64), 0, st, cons_red, upd_red, dstat);
+            M3D_KERNEL_CHECK();
+            return M3D_OK;
+        }
         if ((rc2 = conv(r2, 1, w2, kInCore))) return rc2;  // rlgc.py:664-672
         hipLaunchKernelGGL(k_consensus_in, dim3(g_pad), rb, 0, st, w1, w2, un, hu, g, mm_part);
         M3D_KERNEL_CHECK();
