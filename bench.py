@@ -14,7 +14,10 @@ table).  Default workload = BASELINE.json ``configs[1]``: 64 x 2048 x 2048 tile,
 
 Tiles are independent: every rank decodes its own tile per step (weak scaling, no
 data-path collective; RCCL is only used for the timing barrier / max-reduce here).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  ``roofline`` prices one RLGC iteration (the unit that is launched
+~1600 times per tile) at SURVEY.md section 8(d)'s 148 algorithmic bytes per padded voxel over the
+iteration's device time measured with HIP events inside ``m3d_rlgc_run``; ``roofline_conv`` and
+``roofline_kernels`` break it down, ``roofline_decode`` is the MFMA-bound decode kernel.
 """
 
 from __future__ import annotations
@@ -41,6 +44,7 @@ WORKLOADS = {
     "config2": ((64, 2048, 2048), 22, (64, 51, 51), 80_000),
     "config1": ((16, 256, 256), 16, (16, 51, 51), 1_200),
 }
+RLGC_ALGORITHMIC_BYTES_PER_ITER_VOXEL = 148.0
 RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL = 20.0  # 2 FFTs x 8 B + OTF read 4 B
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -149,11 +153,11 @@ def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
     }
 
 
-def pmc_traffic_per_conv(padded_shape):
-    """HBM bytes per fft_conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 +
-    WRITE_SIZE, profiles/r01_pmc_rlgc_traffic.json, made by scripts/pmc_summary.py) - only for
-    the FFT volume they were collected on, else None.  PMC collection needs its own profiler
-    passes, so this figure is measured offline, not inside this run."""
+def pmc_traffic(padded_shape, key="rlgc_iteration_hbm_bytes"):
+    """HBM bytes per RLGC iteration (or per fft_conv launch) from the committed rocprofv3 PMC
+    passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_pmc_rlgc_traffic.json, made by
+    scripts/pmc_summary.py) - only for the FFT volume they were collected on, else None.  PMC
+    collection needs its own profiler passes, so this figure is measured offline, not in this run."""
     path = Path(__file__).resolve().parent / "profiles" / "r01_pmc_rlgc_traffic.json"
     try:
         d = json.loads(path.read_text())
@@ -161,7 +165,7 @@ def pmc_traffic_per_conv(padded_shape):
         return None
     if abs(d.get("padded_volume_bytes", 0) - 4.0 * float(np.prod(padded_shape))) > 1:
         return None
-    return round(float(d["fft_conv_hbm_bytes_per_launch"]), 1)
+    return round(float(d[key]), 1) if d.get(key) else None
 
 
 def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tuple[float, float]:
@@ -219,7 +223,7 @@ def main() -> None:
     decoder = PD.PixelDecoder(store, merfish_bits=n_bits, verbose=0)
     decon = torch.empty(shape, dtype=torch.float32, device=device)
     stats = {"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "fused": True,
-             "kernel_ms": [0.0] * 5}
+             "kernel_ms": [0.0] * 5, "loop_ms": 0.0}
     t_start = time.perf_counter()
 
     def progress(msg: str) -> None:  # keeps the GPU box's silence watchdog fed
@@ -232,6 +236,7 @@ def main() -> None:
             stats["iters"] += info.iterations
             stats["conv_ms"] += info.conv_ms_total
             stats["conv_calls"] += info.conv_calls
+            stats["loop_ms"] += info.loop_ms
             stats["fused"] = info.fused_engine
             for k in range(5):
                 stats["kernel_ms"][k] += info.kernel_ms[k]
@@ -277,7 +282,8 @@ def main() -> None:
             decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
         else:
             step(False)
-    stats.update({"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "kernel_ms": [0.0] * 5})
+    stats.update({"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "kernel_ms": [0.0] * 5,
+                  "loop_ms": 0.0})
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -293,7 +299,11 @@ def main() -> None:
         padded = [s + a + b for s, (a, b) in zip(shape, pads)]
         np_full = float(np.prod(padded))
         conv_ms = stats["conv_ms"] / max(stats["conv_calls"], 1)
-        achieved = RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full / (conv_ms * 1e-3) / 1e9 if conv_ms else 0.0
+        conv_achieved = RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full / (conv_ms * 1e-3) / 1e9 if conv_ms else 0.0
+        # one RLGC iteration = the launch unit of the dominant work: SURVEY.md section 8(d) prices it at
+        # 148 B per padded voxel (4 convolutions x 20 B + 17 elementwise array passes x 4 B)
+        iter_ms = stats["loop_ms"] / max(float(stats["iters"]), 1.0)  # this rank's loops / this rank's iterations
+        achieved = RLGC_ALGORITHMIC_BYTES_PER_ITER_VOXEL * np_full / (iter_ms * 1e-3) / 1e9 if iter_ms else 0.0
         out = {
             "metric": "Mvoxels/s through decon+decode, 22-bit codebook, 2048^2x64 tile",
             "value": round(value, 4),
@@ -319,16 +329,24 @@ def main() -> None:
             "mvoxel_iterations_per_s": round(total_iters * n_tile / elapsed / 1e6, 2),
             "transcripts_rank0": stats["transcripts"],
             "roofline": {
-                "kernel": ("fft_conv = k_x_forward + k_y_pass + k_z_conv + k_y_pass + k_x_inverse "
-                           "(fused in-LDS FFT convolution, 4 per RLGC iteration)" if stats["fused"] else
-                           "fft_conv (rocFFT r2c + k_cmul + rocFFT c2r), 4 per RLGC iteration"),
+                "kernel": ("one RLGC iteration = 4 x fft_conv (k_x_forward, k_y_pass, k_z_conv, k_y_pass, k_x_inverse; "
+                           "the consensus and update arithmetic runs in two of the k_x_inverse store loops) "
+                           "+ k_split_ratio + 2 one-block finalize kernels"),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic_per_conv(padded),
-                "avg_ms": round(conv_ms, 3),
+                "traffic": pmc_traffic(padded),
+                "avg_ms": round(iter_ms, 3),
+                "launches": int(stats["iters"]),
+                "algorithmic_bytes_per_launch": RLGC_ALGORITHMIC_BYTES_PER_ITER_VOXEL * np_full,
+            },
+            "roofline_conv": {
+                "kernel": "fft_conv (5 kernels, 4 per iteration; two of the four carry fused elementwise tails)",
+                "bound": "hbm", "achieved": round(conv_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(conv_achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc_traffic(padded, "fft_conv_hbm_bytes_per_launch"), "avg_ms": round(conv_ms, 3),
                 "launches": stats["conv_calls"],
                 "algorithmic_bytes_per_launch": RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full,
             },

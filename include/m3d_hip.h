@@ -85,6 +85,8 @@ typedef struct m3d_rlgc_result {
     int32_t fused_engine; /* 1: in-LDS engine (kernel_ms valid), 0: rocFFT                    */
     double kernel_ms[5];  /* profile, fused engine: summed time of k_x_forward, k_y_pass fwd,
                              k_z_conv, k_y_pass inv, k_x_inverse over all timed convolutions  */
+    double loop_ms;       /* profile: device time of the whole iteration loop (first Hu convolution
+                             to the last update), i.e. iterations x everything one iteration runs */
 } m3d_rlgc_result;
 
 /* FFT engine for plans created afterwards: 0 = the fused in-LDS convolution engine

@@ -68,6 +68,7 @@ class RLGCResult(ctypes.Structure):
         ("conv_calls", c_int32),
         ("fused_engine", c_int32),
         ("kernel_ms", ctypes.c_double * 5),
+        ("loop_ms", ctypes.c_double),
     ]
 
 

@@ -493,6 +493,7 @@ struct m3d_rlgc_plan {
         o_fftwork;
     Status *status_host = nullptr;  // pinned
     std::vector<hipEvent_t> events;  // reused across runs when params->profile is set
+    hipEvent_t loop_ev[2] = {nullptr, nullptr};
     m3d::FftConvPlan *fc = nullptr;  // fused in-LDS FFT convolution engine (default)
     void *zeroed_workspace = nullptr;  // spectrum tile padding already cleared in this buffer
 };
@@ -689,6 +690,8 @@ int m3d_rlgc_plan_destroy(m3d_rlgc_plan *p)
     if (p->status_host) (void)hipHostFree(p->status_host);
     m3d::fftconv_destroy(p->fc);
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->loop_ev)
+        if (e) (void)hipEventDestroy(e);
     delete p;
     return M3D_OK;
 }
@@ -890,6 +893,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     int num_iters = 0, stop = 0;
     float *result = nullptr;
 
+    if (elog.enabled) {
+        for (hipEvent_t &e : p->loop_ev)
+            if (!e) M3D_HIP_CHECK(hipEventCreate(&e));
+        M3D_HIP_CHECK(hipEventRecord(p->loop_ev[0], st));
+    }
     if ((rc = enqueue_forward(0))) return rc;
     if ((rc = read_status())) return rc;
     for (;;) {
@@ -947,6 +955,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         }
     }
     if (num_iters == 0 && stop == 1) result = recon_cur;  // cannot happen (prev = inf); safety
+    if (elog.enabled) M3D_HIP_CHECK(hipEventRecord(p->loop_ev[1], st));
     hipLaunchKernelGGL(k_crop, dim3(g_core), rb, 0, st, result, out, g);
     M3D_KERNEL_CHECK();
     M3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -968,6 +977,9 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         }
         res->conv_ms_total = total;
         res->fused_engine = p->fc ? 1 : 0;
+        float loop_ms = 0.0f;
+        if (elog.enabled && hipEventElapsedTime(&loop_ms, p->loop_ev[0], p->loop_ev[1]) != hipSuccess) loop_ms = 0.0f;
+        res->loop_ms = loop_ms;
     }
     return M3D_OK;
 }

@@ -174,6 +174,7 @@ class RLGCInfo:
     conv_calls: int = 0
     fused_engine: bool = True
     kernel_ms: tuple = ()        # profile + fused engine: x fwd, y fwd, z conv, y inv, x inv
+    loop_ms: float = 0.0         # profile: device time of the whole iteration loop
 
 
 def _as_device(array, device, dtype=None):
@@ -290,6 +291,7 @@ def rlgc_device(
         conv_calls=int(result.conv_calls),
         fused_engine=bool(result.fused_engine),
         kernel_ms=tuple(float(v) for v in result.kernel_ms),
+        loop_ms=float(result.loop_ms),
     )
     return out, info
 

@@ -16,13 +16,32 @@ import sys
 CONV = ("k_x_forward", "k_y_pass<false", "k_z_conv", "k_y_pass<true", "k_x_inverse")
 
 
-def load(path):
-    d = collections.defaultdict(list)
+def rows(path):
+    out = []
     for r in csv.DictReader(open(path)):
         m = re.search(r"(k_\w+(?:<[^>]*>)?)", r["Kernel_Name"])
         if m:
-            d[m.group(1)].append(float(r["Counter_Value"]) * 1024.0)
+            out.append((int(r["Dispatch_Id"]), m.group(1), float(r["Counter_Value"]) * 1024.0))
+    out.sort()
+    return out
+
+
+def load(path):
+    d = collections.defaultdict(list)
+    for _i, name, v in rows(path):
+        d[name].append(v)
     return d
+
+
+def per_call_totals(path, scale):
+    """Bytes per m3d_rlgc_run call (k_psf_sum opens each call)."""
+    totals = []
+    for _i, name, v in rows(path):
+        if name.startswith("k_psf_sum"):
+            totals.append(0.0)
+        if totals:
+            totals[-1] += scale * v
+    return totals
 
 
 def main():
@@ -39,18 +58,25 @@ def main():
             "hbm_bytes_corrected_mean": 2.0 * sum(f) / len(f) + sum(w) / len(w),
             "in_padded_f32_volumes": round((2.0 * sum(f) / len(f) + sum(w) / len(w)) / vol, 3),
         }
-    n_conv = len(fetch.get("k_x_inverse<1>", fetch.get("k_x_inverse<0>", [])))
+    n_conv = sum(len(v) for k, v in fetch.items() if k.startswith("k_x_inverse"))
     total = 0.0
     for k, v in kernels.items():
         if k.startswith(CONV):
             total += v["hbm_bytes_corrected_mean"] * v["dispatches"]
+    # the probe runs the solver for 1, n and 2n iterations: the difference of the last two calls is n
+    # iterations' worth of traffic without the per-call setup (OTF, update_norm, speculative forward)
+    calls = [f + w for f, w in zip(per_call_totals(sys.argv[1], 2.0), per_call_totals(sys.argv[2], 1.0))]
+    n_iter = int(sys.argv[6]) if len(sys.argv) > 6 else 2
+    per_iteration = (calls[-1] - calls[-2]) / n_iter if len(calls) >= 2 else None
     out = {
+        "rlgc_call_hbm_bytes": calls,
+        "rlgc_iteration_hbm_bytes": per_iteration,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/gpu_probe_rlgc.py 64 2048 2048 2",
         "correction": "bytes = 2 * FETCH_SIZE[KiB] * 1024 + WRITE_SIZE[KiB] * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
         "calibration": ("k_floor / k_crop / k_image_sum (4- and 2-byte-per-lane streaming reads of known size) confirm the x2; "
                         "the OTF-only k_z_conv dispatch (reads exactly one spectrum = 1.0 volume) shows 0.752 raw, i.e. the x2 "
-                        "over-corrects the 8-byte-per-lane 128-B-segment pattern by 1.5x, and k_x_inverse (reads one spectrum) "
-                        "shows 0.877 raw: treat the corrected figures of those two kernels as upper bounds"),
+                        "over-corrects the 8-byte-per-lane 128-B-segment pattern by 1.5x, and a plain k_x_inverse (reads one "
+                        "spectrum) shows 0.877 raw: treat the corrected figures of those two kernels as upper bounds"),
         "padded_volume_bytes": vol,
         "fft_conv_launches": n_conv,
         "fft_conv_hbm_bytes_per_launch": total / max(n_conv, 1),
