@@ -128,3 +128,48 @@ def test_decode_full_size_is_tiling_invariant_and_matches_oracle_on_samples():
     np.testing.assert_array_equal(table["sums"][full_small][idx], slab["sums"][keep])
     np.testing.assert_array_equal(table["code"][full_small][idx], slab["code"][keep])
     assert keep.sum() > 1000
+
+
+def test_registration_full_size_recovers_a_known_translation():
+    """register_pair_to_fixed and the SOFIMA estimator at 64 x 2048 x 2048 against a known answer:
+    moving(p) = fixed(p + t) for an integer t, so the pull transform is +t and, after the affine,
+    the residual flow must vanish (multiview_registration.py:208-320, sofima_registration.py:524-757)."""
+    kernels = pkg("kernels")
+    mv = pkg("utils.multiview_registration")
+    sf = pkg("utils.sofima_registration")
+    g = torch.Generator(device=DEV).manual_seed(5)
+    vol = torch.zeros(SHAPE, device=DEV)
+    n = vol.numel() // 4000
+    idx = torch.randint(0, vol.numel(), (n,), device=DEV, generator=g)
+    vol.view(-1)[idx] = torch.rand(n, device=DEV, generator=g) * 4000 + 1000
+    fixed = kernels.gaussian_lowpass(vol, (1.5, 2.0, 2.0)) * 30 + 100
+    del vol
+    t = (1, -3, 5)
+    spacing = (0.31, 0.098, 0.098)
+    Tt = np.eye(4, dtype=np.float32)
+    Tt[:3, 3] = [t[i] * spacing[i] for i in range(3)]
+    # moving(p) = fixed(p + t), zero outside (a circular roll would make +-Z/2 shifts indistinguishable)
+    moving = mv.warp_array_to_reference_gpu(fixed, transform_zyx_um=Tt, spacing_zyx_um=spacing, reference_shape=SHAPE)
+    T = mv.register_pair_to_fixed(fixed, moving, spacing_zyx_um=spacing)
+    T = np.asarray(T)
+    np.testing.assert_allclose(T[:3, :3], np.eye(3), atol=1e-6)
+    # reference -> moving pull: fixed(p) = moving(p - t)
+    np.testing.assert_allclose(T[:3, 3] / np.asarray(spacing), [-v for v in t], atol=0.35)
+    # residual flow of an exactly translated copy: warp with the TRUE transform, estimate, expect ~0
+    Ttrue = np.eye(4, dtype=np.float32)
+    Ttrue[:3, 3] = [-t[i] * spacing[i] for i in range(3)]
+    warped = mv.warp_array_to_reference_gpu(moving, transform_zyx_um=Ttrue, spacing_zyx_um=spacing,
+                                            reference_shape=SHAPE)
+    flow, md = sf.estimate_sofima_flow_field_xyz_px(fixed, warped)
+    assert flow.shape == (3, 11, 127, 127) and md["map_stride_zyx_px"] == [5.0, 16.0, 16.0]
+    assert md["status"] in ("ok", "identity_fallback_no_error_improvement")
+    interior = flow[:, 2:-2, 4:-4, 4:-4]
+    assert np.abs(interior).max() < 0.6 and np.sqrt(np.mean(interior ** 2)) < 0.1
+    # and a known residual: shift the warped volume by 2 px in x -> flow x = +2 in the interior
+    shifted = torch.roll(warped, shifts=-2, dims=2)                              # shifted(p) = warped(p + 2 x)
+    flow2, md2 = sf.estimate_sofima_flow_field_xyz_px(fixed, shifted)
+    assert md2["status"] == "ok" and md2["residual_iterations"] == 2
+    inner = flow2[:, 2:-2, 4:-4, 4:-4]
+    # flow maps a reference coordinate to the moving image: fixed(p) = shifted(p - 2 x)
+    np.testing.assert_allclose(np.median(inner[0]), -2.0, atol=0.3)
+    assert abs(np.median(inner[1])) < 0.3 and abs(np.median(inner[2])) < 0.3
