@@ -520,6 +520,11 @@ class DataRegistration:
         this rank's chunk only."""
         if not items:
             return [], False
+        if (not _dist_ready() and min(int(self._num_gpus), len(items)) > 1
+                and getattr(self._datastore, "in_memory", False)):
+            raise RuntimeError("num_gpus > 1 spawns one child process per GPU, whose writes to an in-memory "
+                               "datastore would be lost: use a path-backed datastore, or run one process per GPU "
+                               "under torch.distributed")
         if _dist_ready():
             import torch.distributed as dist
 

@@ -29,6 +29,8 @@ class _Ready:
 
 
 class InMemoryDataStore:
+    in_memory = True  # children of a spawn-per-GPU run would write into their own copies
+
     def __init__(self, *, num_tiles: int, num_rounds: int, num_bits: int, codebook: pd.DataFrame,
                  voxel_size_zyx_um=(0.315, 0.098, 0.098), microscope_type: str = "3D",
                  datastore_path: str | Path = "/tmp/m3d_inmemory_datastore"):

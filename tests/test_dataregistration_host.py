@@ -103,6 +103,9 @@ def test_resume_bookkeeping():
 def test_shares_are_contiguous_ceil_chunks():
     dr = pkg("DataRegistration")
     ds = _store()
+    with pytest.raises(RuntimeError, match="in-memory"):
+        dr.DataRegistration(ds, num_gpus=2, verbose=0)._shares(["a", "b"])
+    ds.in_memory = False   # stands for a path-backed store
     items = [f"r{i}" for i in range(7)]
     for gpus, want in [(1, [items]), (2, [items[:4], items[4:]]), (3, [items[:3], items[3:6], items[6:]]),
                        (16, [[i] for i in items])]:
