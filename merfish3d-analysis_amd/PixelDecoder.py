@@ -16,8 +16,8 @@ to transcript table; the reference bounces every stage through host NumPy.  Devi
                        ranks with one RCCL all-reduce when tiles are sharded across GPUs
 
 The host-side tail of ``decode_all_tiles`` / ``optimize_filtering`` (blank-fraction filter, duplicate
-removal) lives in ``postdecode.py``.  Out of scope here: the LR
-filter, cell assignment from ROIs, chromatic-affine estimation, napari display.
+removal, LR filter) lives in ``postdecode.py``.  Out of scope here:
+cell assignment from ROIs, chromatic-affine estimation, napari display.
 """
 
 from __future__ import annotations
@@ -1113,9 +1113,28 @@ class PixelDecoder:
         self._df_filtered_barcodes = filtered
         self._barcodes_filtered = True
 
+    @staticmethod
+    def _calculate_lr_fdr(df: pd.DataFrame, threshold: float, blank_count: int, barcode_count: int,
+                          verbose: bool = False) -> float:
+        """:3848-3905."""
+        from .postdecode import lr_fdr
+
+        value = lr_fdr(df, threshold, blank_count, barcode_count)
+        if verbose > 1:
+            print(f"threshold: {threshold}")
+            print(f"lr_fdr: {value}")
+        return value
+
     def _filter_all_barcodes_LR(self, lr_fdr_target: float = 0.05) -> None:
-        raise NotImplementedError("the logistic-regression filter (:3907-4057) is not part of this build; "
-                                  "use filter_method='blank_fraction' (the reference's default)")
+        """Logistic-regression blank classifier with an FDR target (:3907-4057)."""
+        from .postdecode import lr_filter
+
+        filtered, threshold = lr_filter(self._df_barcodes_loaded, is_3d=self._is_3D, blank_count=self._blank_count,
+                                        barcode_count=self._barcode_count, lr_fdr_target=lr_fdr_target)
+        if threshold is None and self._verbose >= 1:
+            print("Insufficient Blank barcodes called for filtering.")
+        self._df_filtered_barcodes = filtered
+        self._barcodes_filtered = True
 
     def _remove_duplicates_in_tile_overlap(self, radius: float = 0.75) -> None:
         """:4137-4177."""

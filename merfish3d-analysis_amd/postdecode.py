@@ -4,6 +4,7 @@ Host-side table work, exactly as in the reference (pandas / NumPy / cKDTree on a
 rows; nothing here touches the GPU in the reference either):
 
 * ``blank_fraction_filter``            PixelDecoder.py:3386-3846
+* ``lr_filter`` / ``lr_fdr``             PixelDecoder.py:3848-4057 (scikit-learn, like the reference)
 * ``remove_duplicates_in_tile_overlap`` PixelDecoder.py:4137-4177
 * ``remove_duplicates_within_tile``     PixelDecoder.py:4179-4363
 
@@ -198,6 +199,67 @@ def blank_fraction_filter(barcodes: pd.DataFrame, *, blank_count: int, barcode_c
                         "target_reached": reached, "all_histogram": all_hist, "blank_histogram": blank_hist,
                         "blank_fraction_histogram": fraction, "threshold_sweep": sweep_df})
     return _done()
+
+
+def lr_fdr(df: pd.DataFrame, threshold: float, blank_count: int, barcode_count: int) -> float:
+    """(blank calls / blank codewords) / (coding calls / coding codewords) among rows whose predicted
+    probability exceeds ``threshold`` (all rows for a negative threshold) - PixelDecoder.py:3848-3905."""
+    blank = df["gene_id"].astype("string").str.lower().str.startswith("blank", na=False)
+    if threshold >= 0:
+        positive = df["predicted_probability"] > threshold
+        df["prediction"] = positive
+        coding, noncoding = int((~blank & positive).sum()), int((blank & positive).sum())
+    else:
+        coding, noncoding = int((~blank).sum()), int(blank.sum())
+    if coding <= 0:
+        return np.inf
+    return (noncoding / blank_count) / (coding / (barcode_count - blank_count))
+
+
+_LR_FEATURES_2D = ["area", "signal_mean", "s-b_mean", "distance_min", "magnitude_mean", "inertia_tensor_eigvals-0",
+                   "inertia_tensor_eigvals-1"]
+
+
+def lr_filter(barcodes: pd.DataFrame, *, is_3d: bool, blank_count: int, barcode_count: int,
+              lr_fdr_target: float = 0.05):
+    """(filtered table with ``cell_id = -1``, chosen probability threshold or None) - PixelDecoder.py:3907-4057.
+
+    A logistic regression (liblinear, seed 42) is trained to tell coding from blank calls on a
+    class-balanced 90 % split of standardised features; the probability threshold is the first of
+    0, 0.1, ... meeting the FDR target, refined on a 0.01 grid around it.  With fewer than two blank
+    calls nothing is filtered."""
+    from sklearn.linear_model import LogisticRegression
+    from sklearn.model_selection import train_test_split
+    from sklearn.preprocessing import StandardScaler
+
+    df = barcodes.copy()
+    df["X"] = ~df["gene_id"].astype("string").str.lower().str.startswith("blank", na=False).to_numpy(dtype=bool)
+    features = _LR_FEATURES_2D + (["inertia_tensor_eigvals-2"] if is_3d else [])
+    columns = ["X"] + features
+    coding, blanks = df[df["X"]][columns], df[~df["X"]][columns]
+    if len(blanks) <= 1:
+        out = barcodes.copy()
+        out["cell_id"] = -1
+        return out, None
+    balanced = pd.concat([coding.sample(n=len(blanks), random_state=42), blanks])
+    x_train, _x_test, y_train, _y_test = train_test_split(balanced.drop("X", axis=1), balanced["X"], test_size=0.1,
+                                                          random_state=42)
+    scaler = StandardScaler()
+    model = LogisticRegression(solver="liblinear", random_state=42)
+    model.fit(scaler.fit_transform(x_train), y_train)
+    df["predicted_probability"] = model.predict_proba(scaler.transform(df[features]))[:, 1]
+
+    def first_meeting(grid, default):
+        for threshold in grid:
+            if lr_fdr(df, threshold, blank_count, barcode_count) <= lr_fdr_target:
+                return threshold
+        return default
+
+    coarse = first_meeting(np.arange(0, 1, 0.1), 0)
+    fine = first_meeting(np.arange(coarse - 0.1, coarse + 0.1, 0.01), coarse)
+    out = df[df["predicted_probability"] > fine].copy()
+    out["cell_id"] = -1
+    return out, float(fine)
 
 
 def remove_duplicates_in_tile_overlap(barcodes: pd.DataFrame, radius: float = 0.75):

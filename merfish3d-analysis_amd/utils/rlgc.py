@@ -106,7 +106,10 @@ def _get_plan(device_index: int, image_shape, psf_shape, pad_yx: bool) -> _Plan:
 
     import torch
 
-    key = (int(device_index), tuple(image_shape), tuple(psf_shape), bool(pad_yx))
+    # one plan (= one workspace) per stream: solves issued on different streams may overlap
+    with torch.cuda.device(device_index):
+        stream = int(torch.cuda.current_stream().cuda_stream)
+    key = (int(device_index), tuple(image_shape), tuple(psf_shape), bool(pad_yx), stream)
     plan = _plan_cache.get(key)
     if plan is None:
         lib = _hip.lib()

@@ -675,8 +675,41 @@ def make_postdecode(pdm):
     np.savez_compressed(HERE / "postdecode.npz", **out)
 
 
+def make_postdecode_lr(pdm):
+    """_filter_all_barcodes_LR (PixelDecoder.py:3907-4057) on the synthetic table + shape features."""
+    rng = np.random.default_rng(2024)
+    table, _genes = synthetic_barcode_table(rng)
+    rng2 = np.random.default_rng(99)
+    n = len(table)
+    blank = table["gene_id"].str.startswith("Blank").to_numpy()
+    table["magnitude_mean"] = table["magnitude_mean"].fillna(1.0)
+    table["signal_mean"] = (table["magnitude_mean"] * rng2.uniform(0.8, 1.2, n)).astype(np.float32)
+    table["s-b_mean"] = (table["signal_mean"] - np.where(blank, 0.5, 0.2) * rng2.uniform(0.5, 1.5, n)).astype(np.float32)
+    for k, scale in enumerate((4.0, 2.0, 0.8)):
+        table[f"inertia_tensor_eigvals-{k}"] = rng2.gamma(2.0, scale, n) * np.where(blank, 0.7, 1.0)
+    out = {c: table[c].to_numpy() for c in table.columns if c != "gene_id"}
+    out["is_blank"] = blank
+    for tag, is3d, target in (("3d", True, 0.05), ("2d", False, 0.2)):
+        dec = pdm.PixelDecoder.__new__(pdm.PixelDecoder)
+        dec._df_barcodes_loaded = table.copy()
+        dec._blank_count, dec._barcode_count, dec._verbose, dec._is_3D = 10, 140, 0, is3d
+        dec._filter_all_barcodes_LR(lr_fdr_target=target)
+        out[f"{tag}_kept_rows"] = dec._df_filtered_barcodes.index.to_numpy()
+        out[f"{tag}_probability"] = dec._df_filtered_barcodes["predicted_probability"].to_numpy()
+    few = table[~blank].iloc[:30]
+    dec = pdm.PixelDecoder.__new__(pdm.PixelDecoder)
+    dec._df_barcodes_loaded = few.copy()
+    dec._blank_count, dec._barcode_count, dec._verbose, dec._is_3D = 10, 140, 0, True
+    dec._filter_all_barcodes_LR(lr_fdr_target=0.05)
+    out["noblank_kept_rows"] = dec._df_filtered_barcodes.index.to_numpy()
+    np.savez_compressed(HERE / "postdecode_lr.npz", **out)
+
+
 def main():
     rl, mv, dw, sf, pdm = import_reference()
+    if "--postdecode-lr-only" in sys.argv:
+        make_postdecode_lr(pdm)
+        return
     if "--sofima-jax-only" in sys.argv:
         make_sofima_jax_glue(sf)
         return
@@ -689,6 +722,7 @@ def main():
     make_registration(mv, dw, sf)
     make_sofima_jax_glue(sf)
     make_postdecode(pdm)
+    make_postdecode_lr(pdm)
     print("golden fixtures written to", HERE)
 
 

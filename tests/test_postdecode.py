@@ -169,5 +169,40 @@ def test_pixeldecoder_filter_driver_methods(golden):
         PD.PixelDecoder._validate_filter_configuration("lr", 0.1, 0.05)
     with pytest.raises(ValueError, match="must be one of"):
         PD.PixelDecoder._validate_filter_configuration("other", 0.05, 0.05)
-    with pytest.raises(NotImplementedError):
-        dec._apply_filter_method("lr", 0.05, 0.05)
+
+
+def _lr_table(g):
+    base = np.load(str(__import__("conftest").GOLDEN / "postdecode.npz"))
+    df = pd.DataFrame({"gene_id": base["gene_sorted"][base["gene_code"]]})
+    for c in g.files:
+        if not c.startswith(("3d_", "2d_", "noblank_", "is_blank")):
+            df[c] = g[c]
+    assert (df["gene_id"].str.startswith("Blank").to_numpy() == g["is_blank"]).all()
+    return df
+
+
+def test_lr_filter_matches_reference_run(golden):
+    pd_mod = pkg("postdecode")
+    PD = pkg("PixelDecoder")
+    g = golden("postdecode_lr")
+    table = _lr_table(g)
+    for tag, is3d, target in (("3d", True, 0.05), ("2d", False, 0.2)):
+        out, threshold = pd_mod.lr_filter(table, is_3d=is3d, blank_count=10, barcode_count=140, lr_fdr_target=target)
+        np.testing.assert_array_equal(out.index.to_numpy(), g[f"{tag}_kept_rows"])
+        np.testing.assert_allclose(out["predicted_probability"].to_numpy(), g[f"{tag}_probability"], rtol=1e-12)
+        assert (out["cell_id"] == -1).all() and 0.0 <= threshold < 1.0
+    few = table[~g["is_blank"]].iloc[:30]
+    out, threshold = pd_mod.lr_filter(few, is_3d=True, blank_count=10, barcode_count=140)
+    assert threshold is None
+    np.testing.assert_array_equal(out.index.to_numpy(), g["noblank_kept_rows"])
+    # driver method + FDR helper
+    dec = PD.PixelDecoder.__new__(PD.PixelDecoder)
+    dec._df_barcodes_loaded = table
+    dec._blank_count, dec._barcode_count, dec._verbose, dec._is_3D = 10, 140, 0, True
+    dec._apply_filter_method("lr", 0.05, 0.05)
+    np.testing.assert_array_equal(dec._df_filtered_barcodes.index.to_numpy(), g["3d_kept_rows"])
+    scored = dec._df_filtered_barcodes.copy()
+    blank = scored["gene_id"].str.startswith("Blank")
+    want = (blank.sum() / 10) / ((~blank).sum() / 130)
+    assert PD.PixelDecoder._calculate_lr_fdr(scored, -1.0, 10, 140) == want
+    assert PD.PixelDecoder._calculate_lr_fdr(scored[blank].copy(), 0.0, 10, 140) == np.inf
