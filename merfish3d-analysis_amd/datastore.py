@@ -58,6 +58,7 @@ class InMemoryDataStore:
         self._chromatic = {}
         self._norm_vectors = {}
         self._norm_meta = {}
+        self._norm_decode_mode = {}
         self._decoded = {}
         self._filtered = {}
         self._predictor_spots = {}
@@ -210,13 +211,18 @@ class InMemoryDataStore:
                                           decode_mode=None, metadata=None):
         self._norm_vectors[(decode_run_key, kind)] = (np.asarray(normalization).copy(),
                                                       np.asarray(background).copy())
-        self._norm_meta[(decode_run_key, kind)] = dict(metadata or {}, decode_mode=decode_mode)
+        # the store keeps the metadata mapping as given (qi2labDataStore.py:1229-1232, 1253-1271);
+        # decode_mode is a separate run attribute
+        self._norm_meta[(decode_run_key, kind)] = None if metadata is None else dict(metadata)
+        if decode_mode is not None:
+            self._norm_decode_mode[decode_run_key] = str(decode_mode)
 
     def load_decode_normalization_vectors(self, decode_run_key, kind):
         return self._norm_vectors.get((decode_run_key, kind), (None, None))
 
     def load_decode_normalization_metadata(self, decode_run_key, kind):
-        return self._norm_meta.get((decode_run_key, kind))
+        meta = self._norm_meta.get((decode_run_key, kind))
+        return dict(meta) if meta is not None else None
 
     def decoded_temporary_dir(self, decode_run_key=None):
         return self._datastore_path / "decoded_temp" / str(decode_run_key or "default")

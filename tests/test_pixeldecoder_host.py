@@ -86,3 +86,57 @@ def test_normalization_state_precedence(golden):
     store.save_decode_normalization_vectors(None, "global", np.ones(16, np.float32), np.zeros(16, np.float32))
     dec._prepare_normalization_state("global", True)
     assert dec._global_normalization_loaded and not dec._iterative_normalization_loaded
+
+
+def _decoder_with_codebook():
+    """The three-gene decoder of the reference's test module (tests/test_optimization_codeword_exclusions.py:17-30)."""
+    PD = pkg("PixelDecoder").PixelDecoder
+    dec = PD.__new__(PD)
+    dec._gene_ids = ["GeneA", "GeneB", "GeneC"]
+    dec._codebook_matrix = np.asarray([[1, 1, 0, 0], [1, 0, 1, 0], [1, 0, 0, 1]], dtype=np.int8)
+    return dec
+
+
+def test_resolve_exclusions_is_exact_deduplicated_and_index_stable():
+    """Mirror of the reference test of the same name (:96-104)."""
+    dec = _decoder_with_codebook()
+    gene_ids, indices = dec._resolve_excluded_gene_ids([" GeneB ", "GeneB"])
+    assert gene_ids == ("GeneB",) and indices == (1,)
+    with pytest.raises(ValueError, match="case-sensitive"):
+        dec._resolve_excluded_gene_ids(["geneb"])
+    assert dec._resolve_excluded_gene_ids(None) == ((), ()) and dec._resolve_excluded_gene_ids([]) == ((), ())
+    assert dec._resolve_excluded_gene_ids(["GeneC", "GeneA"]) == (("GeneA", "GeneC"), (2, 0))
+
+
+def test_resolve_exclusions_rejects_removing_entire_codebook():
+    """Mirror of the reference test of the same name (:107-111)."""
+    dec = _decoder_with_codebook()
+    with pytest.raises(ValueError, match="every codeword"):
+        dec._resolve_excluded_gene_ids(["GeneA", "GeneB", "GeneC"])
+
+
+def test_excluded_winner_becomes_background_without_index_fallback():
+    """Mirror of the reference test of the same name (:114-120): torch tensors behave like the arrays."""
+    PD = pkg("PixelDecoder").PixelDecoder
+    decoded = np.asarray([0, 1, 2, 1, -1], dtype=np.int16)
+    nearest = np.asarray([0, 1, 2, 1, 1], dtype=np.int16)
+    PD._suppress_excluded_codeword_assignments(decoded, nearest, (1,))
+    np.testing.assert_array_equal(decoded, np.asarray([0, -1, 2, -1, -1]))
+
+
+def test_run_scoped_normalization_metadata_round_trips():
+    """Mirror of the reference datastore test (:275-300) on the in-memory store double."""
+    ds_mod = pkg("datastore")
+    import pandas as pd
+
+    store = ds_mod.InMemoryDataStore(num_tiles=1, num_rounds=1, num_bits=4,
+                                     codebook=pd.DataFrame({"gene_id": ["a"], "bit01": [1]}))
+    metadata = {"scope": "iterative_optimization", "excluded_gene_ids": ["GeneB"], "codebook_sha256": "abc123"}
+    store.save_decode_normalization_vectors("run1", "iterative", np.ones(4, dtype=np.float32),
+                                            np.zeros(4, dtype=np.float32), decode_mode="3d", metadata=metadata)
+    assert store.load_decode_normalization_metadata("run1", "iterative") == metadata
+    nrm, bkd = store.load_decode_normalization_vectors("run1", "iterative")
+    np.testing.assert_array_equal(nrm, np.ones(4, dtype=np.float32))
+    np.testing.assert_array_equal(bkd, np.zeros(4, dtype=np.float32))
+    assert store.load_decode_normalization_vectors("other", "iterative") is None or \
+        store.load_decode_normalization_vectors("other", "iterative") == (None, None)
