@@ -228,12 +228,12 @@ __device__ __forceinline__ void dft_r(float2 *v)
 template <int R, bool INV>
 __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estride, int batch,
                                           int bstride, const float2 *__restrict__ tw, int tid,
-                                          int nthreads)
+                                          int nthreads, int gmax = 4)
 {
     const int sub = M / R;      // butterflies per block
     const int per_fft = n / R;  // butterflies per transform
     const int twstep = n / M;
-    const int G = batch < 4 ? batch : 4;
+    const int G = batch < gmax ? batch : gmax;  // gmax in {1, 2, 4}
     const int nbg = batch / G;
     const int bshift = __builtin_ctz((unsigned)nbg);
     const int total = per_fft << bshift;
@@ -283,22 +283,22 @@ __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estrid
 template <bool INV, int RSET>
 __device__ __forceinline__ void lds_stage_r(int r, float2 *data, int n, int M, int estride, int batch,
                                             int bstride, const float2 *__restrict__ tw, int tid,
-                                            int nthreads)
+                                            int nthreads, int gmax = 4)
 {
     switch (r) {
 #ifdef M3D_FFT_RADIX27  // costs ~180 VGPRs: halves the resident waves of every pass
-        case 27: lds_stage<27, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+        case 27: lds_stage<27, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
 #endif
         case 16:
-            if constexpr (RSET == 0) lds_stage<16, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads);
+            if constexpr (RSET == 0) lds_stage<16, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax);
             break;
-        case 9: lds_stage<9, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+        case 9: lds_stage<9, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
         case 8:
-            if constexpr (RSET == 0) lds_stage<8, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads);
+            if constexpr (RSET == 0) lds_stage<8, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax);
             break;
-        case 4: lds_stage<4, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
-        case 3: lds_stage<3, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
-        default: lds_stage<2, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads); break;
+        case 4: lds_stage<4, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
+        case 3: lds_stage<3, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
+        default: lds_stage<2, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
     }
 }
 
@@ -306,14 +306,14 @@ __device__ __forceinline__ void lds_stage_r(int r, float2 *data, int n, int M, i
 // unnormalised).  Every thread of the block must call it; ends with a barrier.
 template <bool INV, int RSET = 0>
 __device__ __forceinline__ void lds_fft(float2 *data, const AxisPlan &ap, int estride, int batch,
-                                        int bstride, int tid, int nthreads)
+                                        int bstride, int tid, int nthreads, int gmax = 4)
 {
     const int n = ap.n;
     if (!INV) {
         int M = n;
         for (int s = 0; s < ap.nstages; ++s) {
             const int r = ap.radix[s];
-            lds_stage_r<false, RSET>(r, data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
+            lds_stage_r<false, RSET>(r, data, n, M, estride, batch, bstride, ap.tw, tid, nthreads, gmax);
             M /= r;
             __syncthreads();
         }
@@ -322,7 +322,7 @@ __device__ __forceinline__ void lds_fft(float2 *data, const AxisPlan &ap, int es
         for (int s = ap.nstages - 1; s >= 0; --s) {
             const int r = ap.radix[s];
             M *= r;
-            lds_stage_r<true, RSET>(r, data, n, M, estride, batch, bstride, ap.tw, tid, nthreads);
+            lds_stage_r<true, RSET>(r, data, n, M, estride, batch, bstride, ap.tw, tid, nthreads, gmax);
             __syncthreads();
         }
     }

@@ -50,7 +50,7 @@ struct FftConvPlan {
     void *tables = nullptr;  // one device allocation holding all twiddle / pos tables
     size_t lds_x, lds_y, lds_z;
     int rset_x, rset_y, rset_z;  // 1: lean kernels (no radix 16 / 8 stage on that axis)
-    int ythreads, zthreads;
+    int ythreads, zthreads, xthreads, gx, gy, gz;
 };
 
 }  // namespace m3d
@@ -60,6 +60,7 @@ namespace {
 struct ConvGeo {
     int Zp, Yp, Xp, Xc, TW, nT, RB, P;
     int lTW, lNB, lP;  // log2 of TW, RB/2, P (all powers of two)
+    int GX, GY, GZ;    // transforms one thread carries through a butterfly of each pass
     int64_t plane;
     m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
     m3d::ConvBox mir;      // mirror != 0: the input is the symmetric extension of this box
@@ -77,7 +78,7 @@ __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, in
 
 // ---------------------------------------------------------------- X forward (R2C)
 template <int RSET>
-__global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src, float2 *__restrict__ spec, ConvGeo g,
+__global__ __launch_bounds__(512) void k_x_forward(const float *__restrict__ src, float2 *__restrict__ spec, ConvGeo g,
                             AxisPlan ax)
 {
     extern __shared__ float2 lds_fx[];
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void k_x_forward(const float *__restrict__ src
         }
     }
     __syncthreads();
-    lds_fft<false, RSET>(lds_fx, ax, 1, nb, N, tid, nt);
+    lds_fft<false, RSET>(lds_fx, ax, 1, nb, N, tid, nt, g.GX);
     // Hermitian split: A[k] = (C[k] + conj(C[N-k])) / 2, B[k] = (C[k] - conj(C[N-k])) / (2i)
     const int total = (g.nT << g.lNB) << g.lTW;
     for (int e0 = tid; e0 < total; e0 += nt * kU) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void x_inverse_epilogue(const float2 *lds, const Conv
 
 // ---------------------------------------------------------------- X inverse (C2R)
 template <int RSET, int EPI>
-__global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__ dst, ConvGeo g,
+__global__ __launch_bounds__(512) void k_x_inverse(const float2 *__restrict__ spec, float *__restrict__ dst, ConvGeo g,
                             AxisPlan ax, m3d::ConvEpilogue ep)
 {
     extern __shared__ float2 lds_ix[];
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_x_inverse(const float2 *__restrict__ sp
         }
     }
     __syncthreads();
-    lds_fft<true, RSET>(lds_ix, ax, 1, nb, N, tid, nt);
+    lds_fft<true, RSET>(lds_ix, ax, 1, nb, N, tid, nt, g.GX);
     if constexpr (EPI == m3d::ConvEpilogue::kNone) {
         for (int bi = 0; bi < nb; ++bi) {
             const int ya = y0 + 2 * bi, yb = ya + 1;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
         for (int i = tid; i < n; i += nt) lds_y[i] = (i >= lo && i < hi) ? tile[i] : make_float2(0.f, 0.f);
     }
     __syncthreads();
-    lds_fft<INV, RSET>(lds_y, ay, g.TW, g.TW, 1, tid, nt);
+    lds_fft<INV, RSET>(lds_y, ay, g.TW, g.TW, 1, tid, nt, g.GY);
     if ((g.TW & 1) == 0) {
         float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
         for (int i = slo / 2 + tid; i < shi / 2; i += nt) t4[i] = l4[i];
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
         }
     }
     __syncthreads();
-    lds_fft<false, RSET>(lds_z, az, P, P, 1, tid, nt);
+    lds_fft<false, RSET>(lds_z, az, P, P, 1, tid, nt, g.GZ);
     if (mode < 0) {
         for (int z = z0; z < g.Zp; z += zstep)
             if (live) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
         }
     }
     __syncthreads();
-    lds_fft<true, RSET>(lds_z, az, P, P, 1, tid, nt);
+    lds_fft<true, RSET>(lds_z, az, P, P, 1, tid, nt, g.GZ);
     for (int z = z0; z < g.Zp; z += zstep)  // only the planes the output needs
         if (live && z >= g.out.z0 && z < g.out.z0 + g.out.nz) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
 }
@@ -460,6 +461,9 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
     g.lNB = __builtin_ctz((unsigned)(p->RB / 2));
     g.lP = __builtin_ctz((unsigned)p->P);
     g.plane = p->plane;
+    g.GX = p->gx;
+    g.GY = p->gy;
+    g.GZ = p->gz;
     return g;
 }
 
@@ -506,6 +510,10 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->P = knob("M3D_FFT_P", 16);
     while (p->P > 1 && (size_t)Zp * p->P * sizeof(float2) > 64 * 1024) p->P /= 2;
     p->lds_z = (size_t)Zp * p->P * sizeof(float2);
+    p->xthreads = knob("M3D_FFT_XT", 256);
+    p->gx = knob("M3D_FFT_GX", 4);
+    p->gy = knob("M3D_FFT_GY", 4);
+    p->gz = knob("M3D_FFT_GZ", 4);
     p->ythreads = knob("M3D_FFT_YT", 768);
     p->zthreads = std::max(p->P, knob("M3D_FFT_ZT", 128));
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
@@ -599,9 +607,9 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
     const int groups = row_groups(p, g.in);
     if (log && log->record()) return M3D_ERR_HIP;
     if (p->rset_x)
-        hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
+        hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
     else
-        hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(256), p->lds_x, st, src, spec, g, p->ax);
+        hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
     if (log && log->record()) return M3D_ERR_HIP;
     if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
@@ -656,7 +664,7 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
         hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     if (log && log->record()) return M3D_ERR_HIP;
     const int groups = row_groups(p, g.out);
-    const dim3 xg((unsigned)(g.out.nz * groups)), xb(256);
+    const dim3 xg((unsigned)(g.out.nz * groups)), xb(p->xthreads);
     ConvEpilogue ep = {};
     if (epilogue) ep = *epilogue;
     if (ep.kind != ConvEpilogue::kNone && (!ep.a || !ep.b || !ep.o1 || !ep.red ||
