@@ -114,3 +114,40 @@ def test_philox_known_answer_and_binomial_moments():
     assert s.min() >= 0 and s.max() <= 300
     edge = philox.binomial_half(np.array([0, 1, 127, 128, 129, 65535]), np.arange(6), 0, 1)
     assert edge[0] == 0 and edge[1] in (0, 1) and 20000 < edge[5] < 45000
+
+
+@pytest.mark.parametrize("is3d", [True, False])
+def test_ccl_oracle_agrees_with_scipy_labelling(is3d):
+    """scikit-image / cuCIM are not installed; SciPy's ``ndimage.label`` with a full structuring element is
+    the same partition (skimage documents connectivity = ndim as the full neighbourhood), labelled per
+    codeword and renumbered in raster order of each region's first voxel."""
+    import scipy.ndimage as ndi
+
+    from oracle import ccl_ref
+
+    rng = np.random.default_rng(17)
+    dec = rng.integers(-1, 4, size=(6, 17, 19)).astype(np.int16)
+    dec[rng.uniform(size=dec.shape) < 0.45] = -1
+    labels, n = ccl_ref.label_equal(dec, is_3d=is3d)
+    want = np.zeros(dec.shape, dtype=np.int64)
+    planes = [slice(None)] if is3d else [slice(z, z + 1) for z in range(dec.shape[0])]
+    structure = np.ones((3, 3, 3))
+    if not is3d:
+        structure[0] = structure[2] = 0      # 8-connectivity inside the plane only
+    nxt = 0
+    for sl in planes:
+        for code in np.unique(dec[sl][dec[sl] >= 0]):
+            lab, k = ndi.label(dec[sl] == code, structure=structure)
+            want[sl][lab > 0] = lab[lab > 0] + nxt
+            nxt += k
+    assert n == nxt
+    # same partition <=> a bijection between the two label sets over the foreground
+    fg = dec >= 0
+    pairs = np.unique(np.stack([labels[fg], want[fg]]), axis=1)
+    assert pairs.shape[1] == n and np.unique(pairs[0]).size == n and np.unique(pairs[1]).size == n
+    assert (labels[~fg] == 0).all()
+    # scikit-image numbering: labels increase with the raster position of each region's first voxel
+    # (per plane with a running offset in the 2-D mode)
+    first = np.full(n + 1, dec.size, dtype=np.int64)
+    np.minimum.at(first, labels.ravel(), np.arange(dec.size))
+    assert (np.diff(first[1:]) > 0).all()
