@@ -215,7 +215,7 @@ def main() -> None:
     codebook = hw4_codebook(n_bits)
     bits_matrix = codebook.iloc[:, 1:].to_numpy(dtype=np.int64)
     psf = gaussian_psf(psf_shape, (1.8, 1.6, 1.6), device)
-    readouts, predictors, _truth = make_tile(shape, bits_matrix, n_emitters, 1 + rank, device, kernels)
+    readouts, predictors, truth = make_tile(shape, bits_matrix, n_emitters, 1 + rank, device, kernels)
     print(f"[bench] rank {rank}: synthetic tile ready", file=sys.stderr, flush=True)
 
     store = DS.InMemoryDataStore(num_tiles=1, num_rounds=1, num_bits=n_bits, codebook=codebook)
@@ -249,6 +249,7 @@ def main() -> None:
         deconvolve_bits(profile)
         decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
         stats["transcripts"] = len(decoder.decoded_barcodes)
+        stats["table"] = decoder.decoded_barcodes[["tile_z", "tile_y", "tile_x", "barcode_id"]]
         progress(f"decode_one_tile: {stats['transcripts']} transcripts")
 
     def fix_normalization() -> None:
@@ -370,6 +371,15 @@ def main() -> None:
                  "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
                  "bytes_per_voxel": round(bpv, 2)}
                 for nme, ms, bpv in zip(names, stats["kernel_ms"], moved)]
+        # sanity of the decoded table against the planted emitters (voxel units, 3-voxel radius, same
+        # codeword, one-to-one): the scorer of the simulation pipeline, not a timed quantity
+        scoring = importlib.import_module("merfish3d-analysis_amd.scoring")
+        table = stats.get("table")
+        if table is not None:
+            f1 = scoring.calculate_F1_with_radius(
+                table[["tile_z", "tile_y", "tile_x"]].to_numpy(dtype=float), table["barcode_id"].to_numpy() - 1,
+                truth[:, 1:4].astype(float), truth[:, 0], 3.0)[0]
+            out["f1_vs_planted_emitters"] = {k: (round(v, 4) if isinstance(v, float) else int(v)) for k, v in f1.items()}
         # the one dense contraction of the path, outside the timed region: the fused decode kernel
         # (exact-f32 MFMA distance step) on this tile's low-passed bit stack, HIP events on the
         # stream it is launched on
