@@ -92,7 +92,8 @@ def _experiment(seed=0):
     return store, truth, shifts, predictors
 
 
-def test_preprocess_then_decode_recovers_the_planted_transcripts():
+@pytest.mark.parametrize("deformable", [False, True])
+def test_preprocess_then_decode_recovers_the_planted_transcripts(deformable):
     DR, PD, sc = pkg("DataRegistration"), pkg("PixelDecoder"), pkg("scoring")
     store, truth, shifts, predictors = _experiment()
     state = {}
@@ -113,8 +114,8 @@ def test_preprocess_then_decode_recovers_the_planted_transcripts():
         return load(tile, round=round, bit=bit, return_future=return_future)
 
     store.load_local_corrected_image = tracking_load
-    reg = DR.DataRegistration(store, decon_fiducial=True, decon_readout=True, perform_deformable_registration=False,
-                              verbose=0, feature_predictor=predictor)
+    reg = DR.DataRegistration(store, decon_fiducial=True, decon_readout=True,
+                              perform_deformable_registration=deformable, verbose=0, feature_predictor=predictor)
     reg.register_all_tiles()
     store.load_local_corrected_image = load
     for tile in store.tile_ids:
@@ -122,6 +123,12 @@ def test_preprocess_then_decode_recovers_the_planted_transcripts():
             T = store.load_local_round_transform_zyx_um(tile, rid)
             np.testing.assert_allclose(T[:3, 3] / np.asarray(VOXEL), shifts[r], atol=0.4, err_msg=f"{tile} {rid}")
     assert reg._is_tile_complete(store.tile_ids[0]) and reg._is_tile_complete(store.tile_ids[1])
+    for tile in store.tile_ids:
+        for rid in store.round_ids[1:]:
+            saved = store.load_local_sofima_flow_field(tile, rid)
+            assert (saved is not None) == deformable
+            if deformable:   # rigid shifts only: whatever residual field is kept stays small
+                assert saved[0].shape[0] == 3 and np.abs(saved[0]).max() < 2.5, np.abs(saved[0]).max()
 
     dec = PD.PixelDecoder(store, merfish_bits=N_BITS, verbose=0)
     dec._global_normalization_vectors(gpu_id=0)
