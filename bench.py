@@ -51,17 +51,22 @@ HBM_PEAK_GBS = 8000.0
 
 
 def hw4_codebook(n_bits: int, n_codes: int = 140, n_blank: int = 10, seed: int = 0) -> pd.DataFrame:
-    """Greedy weight-4 / Hamming-distance-4 codebook (MHD4 family used by the reference data)."""
+    """Weight-4 / Hamming-distance-4 codebook (MHD4 family used by the reference data).  16 bits: the 140
+    blocks of the Steiner quadruple system on GF(2)^4 (4-subsets XOR-ing to zero, the optimum A(16,4,4));
+    other lengths: a seeded greedy selection."""
     rng = np.random.default_rng(seed)
     combos = list(itertools.combinations(range(n_bits), 4))
-    rng.shuffle(combos)
     chosen: list[tuple] = []
-    for c in combos:
-        s = set(c)
-        if all(len(s & set(o)) <= 2 for o in chosen):
-            chosen.append(c)
-        if len(chosen) == n_codes:
-            break
+    if n_bits == 16:
+        chosen = [c for c in combos if c[0] ^ c[1] ^ c[2] ^ c[3] == 0][:n_codes]
+    else:
+        rng.shuffle(combos)
+        for c in combos:
+            s = set(c)
+            if all(len(s & set(o)) <= 2 for o in chosen):
+                chosen.append(c)
+            if len(chosen) == n_codes:
+                break
     bits = np.zeros((len(chosen), n_bits), dtype=np.int64)
     for i, c in enumerate(chosen):
         bits[i, list(c)] = 1
@@ -176,6 +181,8 @@ def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tu
         return float(elapsed), float(iters)
     import torch.distributed as dist
 
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     it = torch.tensor([iters], dtype=torch.float64, device=device)
@@ -197,12 +204,19 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # M3D_BENCH_BACKEND=gloo is a rehearsal switch (several ranks sharing one GPU on a one-GPU box,
+    # which RCCL refuses); the measured configuration is always one rank per GPU over RCCL
+    backend = os.environ.get("M3D_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(gpu_index)
+    device = torch.device("cuda", gpu_index)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__  # noqa: F401  (puts the repo root on sys.path)
 
@@ -247,7 +261,7 @@ def main() -> None:
 
     def step(profile: bool) -> None:
         deconvolve_bits(profile)
-        decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
+        decoder.decode_one_tile(tile_idx=0, gpu_id=gpu_index, normalization_method="global")
         stats["transcripts"] = len(decoder.decoded_barcodes)
         stats["table"] = decoder.decoded_barcodes[["tile_z", "tile_y", "tile_x", "barcode_id"]]
         progress(f"decode_one_tile: {stats['transcripts']} transcripts")
@@ -257,8 +271,8 @@ def main() -> None:
         normalisation = 99.9th percentile (minus background) of each bit's low-passed
         readout x predictor product (exact radix select on the device)."""
         decoder._tile_idx = 0
-        decoder._load_bit_data(gpu_id=local_rank)
-        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=local_rank)
+        decoder._load_bit_data(gpu_id=gpu_index)
+        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=gpu_index)
         bkd = np.zeros(n_bits, dtype=np.float32)
         nrm = np.ones(n_bits, dtype=np.float32)
         for b in range(n_bits):
@@ -282,7 +296,7 @@ def main() -> None:
         if w == 0:
             deconvolve_bits(False)
             fix_normalization()
-            decoder.decode_one_tile(tile_idx=0, gpu_id=local_rank, normalization_method="global")
+            decoder.decode_one_tile(tile_idx=0, gpu_id=gpu_index, normalization_method="global")
         else:
             step(False)
     stats.update({"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "kernel_ms": [0.0] * 5,
@@ -384,15 +398,15 @@ def main() -> None:
         # (exact-f32 MFMA distance step) on this tile's low-passed bit stack, HIP events on the
         # stream it is launched on
         decoder._tile_idx = 0
-        decoder._load_global_normalization_vectors(gpu_id=local_rank)
-        decoder._load_bit_data(gpu_id=local_rank)
-        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=local_rank)
-        decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=local_rank)
+        decoder._load_global_normalization_vectors(gpu_id=gpu_index)
+        decoder._load_bit_data(gpu_id=gpu_index)
+        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=gpu_index)
+        decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=gpu_index)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         reps = 3
         ev[0].record()
         for _ in range(reps):
-            decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=local_rank)
+            decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=gpu_index)
         ev[1].record()
         torch.cuda.synchronize(device)
         dec_ms = ev[0].elapsed_time(ev[1]) / reps
