@@ -84,4 +84,16 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
 // symmetric extension to the whole volume (np.pad mode="symmetric", rlgc.py:203-271) - the
 // X pass gathers through the index map instead of reading a materialised pad region.
 
+// fft_conv without its X inverse pass: afterwards `spec` holds the half spectrum along x of every
+// (z, y) row of the result (rows of `out_box` only).  Records five events when logging.
+int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
+                    void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
+                    const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr);
+// The X inverse pass shared by two such results that meet in the consensus arithmetic: the same row of
+// both spectra is one packed complex row (S1 + i S2), one inverse transform returns both real rows and
+// ConvEpilogue::kConsensus runs on them in registers (`a` unused: HT1's numerator is the first result).
+// Neither convolution result reaches HBM.  Records one event when logging.
+int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const float2 *spec2, void *stream,
+                           EventLog *log, const ConvEpilogue *epilogue);
+
 }  // namespace m3d

@@ -291,6 +291,89 @@ __global__ __launch_bounds__(512) void k_x_inverse(const float2 *__restrict__ sp
     }
 }
 
+// ---------------------------------------------------------------- dual X inverse (two results, one pass)
+__device__ __forceinline__ void dual_consensus_epilogue(const float2 *lds, const ConvGeo &g, const m3d::ConvEpilogue &ep,
+                                                        int z, int y0, int nb, int N, int tid, int nt)
+{
+#pragma clang fp contract(off)
+    __shared__ float smf[4];
+    constexpr int kU = 4;
+    float mn = INFINITY, mx = -INFINITY;
+    const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
+    for (int bi = 0; bi < nb; ++bi) {
+        const int y = y0 + bi;
+        if (y >= g.Yp) break;
+        const int64_t row = ((int64_t)z * g.Yp + y) * N;
+        const bool yz_core = z_core && y >= ep.core.y0 && y < ep.core.y0 + ep.core.ny;
+        for (int n0 = tid; n0 < N; n0 += nt * kU) {
+            float un[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) un[u] = ep.b[row + min(n0 + u * nt, N - 1)];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int n = n0 + u * nt;
+                if (n >= N) continue;
+                const float2 v = lds[bi * N + n];  // (HTratio1 raw, HTratio2 raw)
+                const float h1 = v.x / un[u], h2 = v.y / un[u];
+                ep.o1[row + n] = (h1 - 1.0f) * (h2 - 1.0f);
+                const float hs = h1 + h2;
+                mn = fminf(mn, hs);
+                mx = fmaxf(mx, hs);
+                if (yz_core && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[row + n] = hs;
+            }
+        }
+    }
+    mn = block_min(mn, smf);
+    mx = block_max(mx, smf);
+    if (tid == 0) {
+        atomicMin(&ep.red[0], m3d::float_key(mn));
+        atomicMax(&ep.red[1], m3d::float_key(mx));
+    }
+}
+
+// Full output box only (the consensus input is needed on the whole padded volume).
+template <int RSET>
+__global__ __launch_bounds__(512) void k_x_inverse_dual(const float2 *__restrict__ spec1,
+                                                        const float2 *__restrict__ spec2, ConvGeo g, AxisPlan ax,
+                                                        m3d::ConvEpilogue ep)
+{
+    extern __shared__ float2 lds_id[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int nb = g.RB / 2, N = g.Xp;  // nb rows per block, one packed transform each
+    const int groups = (g.Yp + nb - 1) / nb;
+    const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * nb;
+    const int total = (g.nT << g.lNB) << g.lTW;
+    constexpr int kU = M3D_KU_XI;
+    for (int e0 = tid; e0 < total; e0 += nt * kU) {
+        float2 Av[kU], Bv[kU];
+        int p1[kU], p2[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = min(e0 + u * nt, total - 1);
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int k = min((kt << g.lTW) + kk, g.Xc - 1);
+            p1[u] = ax.pos[k];
+            p2[u] = ax.pos[k == 0 ? 0 : N - k];
+            const int64_t idx = spec_index(g, z, min(y0 + bi, g.Yp - 1), k);
+            Av[u] = spec1[idx];
+            Bv[u] = spec2[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + u * nt;
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int k = (kt << g.lTW) + kk;
+            if (e >= total || k >= g.Xc) continue;
+            const float2 A = Av[u], B = Bv[u];
+            lds_id[bi * N + p1[u]] = make_float2(A.x - B.y, A.y + B.x);
+            if (k != 0 && 2 * k != N) lds_id[bi * N + p2[u]] = make_float2(A.x + B.y, B.x - A.y);
+        }
+    }
+    __syncthreads();
+    lds_fft<true, RSET>(lds_id, ax, 1, nb, N, tid, nt, g.GX);
+    dual_consensus_epilogue(lds_id, g, ep, z, y0, nb, N, tid, nt);
+}
+
 // ---------------------------------------------------------------- Y pass (in place)
 template <bool INV, int RSET>
 __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, ConvGeo g, AxisPlan ay)
@@ -568,6 +651,8 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     (void)hipFuncSetAttribute((const void *)k_x_forward<0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_forward<1>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 1>, attr, (int)p->lds_x);
@@ -640,9 +725,9 @@ static bool box_ok(const FftConvPlan *p, const ConvBox *b)
                   b->y0 + b->ny <= p->Yp && b->x0 >= 0 && b->nx > 0 && b->x0 + b->nx <= p->Xp);
 }
 
-int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
-                 float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
-                 const ConvBox *mirror_box, const ConvEpilogue *epilogue)
+int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
+                    void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
+                    const ConvBox *mirror_box)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!box_ok(p, in_box) || !box_ok(p, out_box) || !box_ok(p, mirror_box) || (in_box && mirror_box))
@@ -663,6 +748,37 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
     else
         hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     if (log && log->record()) return M3D_ERR_HIP;
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const float2 *spec2, void *stream,
+                           EventLog *log, const ConvEpilogue *epilogue)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!spec1 || !spec2 || !epilogue || epilogue->kind != ConvEpilogue::kConsensus || !epilogue->b ||
+        !epilogue->o1 || !epilogue->o2 || !epilogue->red)
+        return M3D_ERR_INVALID_ARG;
+    const ConvGeo g = geo_of(p);
+    const int nb = p->RB / 2;
+    const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->xthreads);
+    if (p->rset_x)
+        hipLaunchKernelGGL(k_x_inverse_dual<1>, grid, block, p->lds_x, st, spec1, spec2, g, p->ax, *epilogue);
+    else
+        hipLaunchKernelGGL(k_x_inverse_dual<0>, grid, block, p->lds_x, st, spec1, spec2, g, p->ax, *epilogue);
+    if (log && log->record()) return M3D_ERR_HIP;
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
+                 float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
+                 const ConvBox *mirror_box, const ConvEpilogue *epilogue)
+{
+    hipStream_t st = (hipStream_t)stream;
+    int rc = fftconv_to_rows(p, src, otf, mode, spec, stream, log, in_box, out_box, mirror_box);
+    if (rc) return rc;
+    const ConvGeo g = geo_of(p, in_box, out_box);
     const int groups = row_groups(p, g.out);
     const dim3 xg((unsigned)(g.out.nz * groups)), xb(p->xthreads);
     ConvEpilogue ep = {};

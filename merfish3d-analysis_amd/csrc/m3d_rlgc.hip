@@ -662,7 +662,7 @@ int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], i
     p->o_r1 = take(fb);
     p->o_r2 = take(fb);
     p->o_w1 = take(fb);
-    p->o_w2 = take(fb);
+    p->o_w2 = take(fb > cb ? fb : cb);  // doubles as the second scratch spectrum of the dual X inverse pass
     p->o_part = take(sizeof(KlPartial) * (size_t)(kRowGrid + kMaxGrid) * 2);
     p->o_status = take(sizeof(Status));
     p->o_fftwork = take(p->fft_work ? p->fft_work : 256);
@@ -738,6 +738,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         // tile padding of the two spectra (kx >= Xc in the last tile) must hold finite values
         M3D_HIP_CHECK(hipMemsetAsync(otf, 0, p->spec_bytes, st));
         M3D_HIP_CHECK(hipMemsetAsync(cbuf, 0, p->spec_bytes, st));
+        M3D_HIP_CHECK(hipMemsetAsync(w2, 0, p->spec_bytes, st));  // second scratch spectrum (dual X inverse)
         p->zeroed_workspace = workspace;
     }
     const float inv_n = 1.0f / (float)g.Np;
@@ -856,12 +857,19 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     };
     auto enqueue_update = [&]() -> int {
         int rc2;
-        if ((rc2 = conv(r1, 1, w1, kInCore))) return rc2;  // HTratio1 * update_norm, rlgc.py:654-662
+        if (!fused_tail && (rc2 = conv(r1, 1, w1, kInCore))) return rc2;  // HTratio1 * update_norm, rlgc.py:654-662
         if (fused_tail) {
-            // HTratio2 (rlgc.py:664-672) never reaches memory: its X inverse pass writes the consensus
-            // input and HT1 + HT2 directly; likewise the consensus map feeds the gated update in place
-            const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, w1, un, hu, w1, cons_red, core};
-            if ((rc2 = conv(r2, 1, w2, kInCore, &e1))) return rc2;
+            // Neither HTratio (rlgc.py:654-672) reaches memory: both convolutions stop in front of their X
+            // inverse pass, which they share - one packed transform per row returns both results and the
+            // consensus input and HT1 + HT2 are written from registers; likewise the consensus map feeds
+            // the gated update in place.
+            float2 *cbuf2 = (float2 *)w2;  // w2 itself is never materialised on this path
+            const m3d::ConvBox *in = &core;
+            if ((rc2 = m3d::fftconv_to_rows(p->fc, r1, otf, 1, cbuf, st, &elog, in, nullptr, nullptr))) return rc2;
+            if ((rc2 = stamp())) return rc2;  // keeps six events per convolution (zero-length X inverse)
+            if ((rc2 = m3d::fftconv_to_rows(p->fc, r2, otf, 1, cbuf2, st, &elog, in, nullptr, nullptr))) return rc2;
+            const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, nullptr, un, hu, w1, cons_red, core};
+            if ((rc2 = m3d::fftconv_dual_consensus(p->fc, cbuf, cbuf2, st, &elog, &e1))) return rc2;
             const m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr,
                                           upd_red, core};
             if ((rc2 = conv(hu, 2, w2, kOutCore, &e2))) return rc2;
