@@ -7,13 +7,18 @@
 
 namespace m3d {
 
-// Optional HIP-event log (bench.py roofline): record() drops an event on the stream.
+// Optional HIP-event log (bench.py roofline).  mark(kind) drops an event on the stream; the time since
+// the previous event is attributed to `kind`: kStart opens a span (nothing attributed), kXF..kXI are the
+// five passes of the fused engine, kWhole a convolution timed as one piece (rocFFT path).
 struct EventLog {
+    enum Kind { kStart = -1, kXF = 0, kYF = 1, kZ = 2, kYI = 3, kXI = 4, kWhole = 5 };
     std::vector<hipEvent_t> *events = nullptr;
+    std::vector<int> kinds;
     size_t used = 0;
+    int convolutions = 0;  // counted by the callers
     hipStream_t stream = nullptr;
     bool enabled = false;
-    int record()
+    int mark(int kind)
     {
         if (!enabled) return 0;
         if (used == events->size()) {
@@ -21,6 +26,7 @@ struct EventLog {
             if (hipEventCreate(&e) != hipSuccess) return -3;
             events->push_back(e);
         }
+        kinds.push_back(kind);
         return hipEventRecord((*events)[used++], stream) == hipSuccess ? 0 : -3;
     }
 };
@@ -75,7 +81,7 @@ __host__ __device__ inline float key_float(unsigned int k)
 
 // dst <- irfftn(rfftn(src) * H) with H = otf (mode 0), conj(otf) (1), |otf|^2 (2);
 // `spec` is a scratch spectrum.  src may equal dst.
-// With an enabled `log`, six events bracket the five kernels (x fwd, y fwd, z conv, y inv, x inv).
+// With an enabled `log` every kernel's time is attributed to its pass (EventLog::Kind).
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                  const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr,
@@ -85,14 +91,14 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
 // X pass gathers through the index map instead of reading a materialised pad region.
 
 // fft_conv without its X inverse pass: afterwards `spec` holds the half spectrum along x of every
-// (z, y) row of the result (rows of `out_box` only).  Records five events when logging.
+// (z, y) row of the result (rows of `out_box` only).
 int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                     void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                     const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr);
 // The X inverse pass shared by two such results that meet in the consensus arithmetic: the same row of
 // both spectra is one packed complex row (S1 + i S2), one inverse transform returns both real rows and
 // ConvEpilogue::kConsensus runs on them in registers (`a` unused: HT1's numerator is the first result).
-// Neither convolution result reaches HBM.  Records one event when logging.
+// Neither convolution result reaches HBM.
 int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const float2 *spec2, void *stream,
                            EventLog *log, const ConvEpilogue *epilogue);
 

@@ -690,12 +690,12 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
 {
     const ConvGeo g = geo_of(p, in_box, nullptr, mirror_box);
     const int groups = row_groups(p, g.in);
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
     if (p->rset_x)
         hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
     else
         hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
     if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     else
@@ -734,7 +734,7 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
         return M3D_ERR_INVALID_ARG;
     int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box);
     if (rc) return rc;
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
     const ConvGeo g = geo_of(p, in_box, out_box);
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
@@ -742,12 +742,12 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
         hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
     else
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
     if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<true, 1>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     else
         hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -766,7 +766,7 @@ int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const floa
         hipLaunchKernelGGL(k_x_inverse_dual<1>, grid, block, p->lds_x, st, spec1, spec2, g, p->ax, *epilogue);
     else
         hipLaunchKernelGGL(k_x_inverse_dual<0>, grid, block, p->lds_x, st, spec1, spec2, g, p->ax, *epilogue);
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -798,7 +798,7 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
         else M3D_LAUNCH_XI(0, 0);
     }
 #undef M3D_LAUNCH_XI
-    if (log && log->record()) return M3D_ERR_HIP;
+    if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }

@@ -762,8 +762,8 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     elog.events = &p->events;
     elog.stream = st;
     elog.enabled = params->profile != 0;
-    auto stamp = [&]() -> int {
-        if (elog.record()) {
+    auto stamp = [&](int kind) -> int {
+        if (elog.mark(kind)) {
             set_err("hipEventRecord", "profiling event");
             return M3D_ERR_HIP;
         }
@@ -784,19 +784,20 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     unsigned int *cons_red = (unsigned int *)mm_part, *upd_red = (unsigned int *)up_part;
     auto conv = [&](float *src, int mode, float *dst, int support = kFull,
                     const m3d::ConvEpilogue *epi = nullptr) -> int {
-        if (p->fc)  // six events per convolution: one in front of and one behind each kernel
+        ++elog.convolutions;
+        if (p->fc)  // every kernel's time is attributed to its pass
             return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog,
                                      prune && (support & kInCore) ? &core : nullptr,
                                      prune && (support & kOutCore) ? &core : nullptr,
                                      prune && (support & kMirrorIn) ? &core : nullptr, epi);
-        int rc = stamp();
+        int rc = stamp(m3d::EventLog::kStart);
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
         hipLaunchKernelGGL(k_cmul, dim3(grid_for(g.Nc)), dim3(kBlock), 0, st, cbuf, otf, g.Nc,
                            mode, inv_n);
         M3D_KERNEL_CHECK();
         if ((rc = fft_c2r(cbuf, dst))) return rc;
-        return stamp();
+        return stamp(m3d::EventLog::kWhole);
     };
     int rc;
 
@@ -865,8 +866,8 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             // the gated update in place.
             float2 *cbuf2 = (float2 *)w2;  // w2 itself is never materialised on this path
             const m3d::ConvBox *in = &core;
+            elog.convolutions += 2;
             if ((rc2 = m3d::fftconv_to_rows(p->fc, r1, otf, 1, cbuf, st, &elog, in, nullptr, nullptr))) return rc2;
-            if ((rc2 = stamp())) return rc2;  // keeps six events per convolution (zero-length X inverse)
             if ((rc2 = m3d::fftconv_to_rows(p->fc, r2, otf, 1, cbuf2, st, &elog, in, nullptr, nullptr))) return rc2;
             const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, nullptr, un, hu, w1, cons_red, core};
             if ((rc2 = m3d::fftconv_dual_consensus(p->fc, cbuf, cbuf2, st, &elog, &e1))) return rc2;
@@ -971,17 +972,16 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         res->iterations = num_iters;
         res->stop_reason = stop;
         const std::vector<hipEvent_t> &ev = p->events;
-        const size_t per = p->fc ? 6 : 2;
-        res->conv_calls = (int32_t)(elog.used / per);
+        res->conv_calls = (int32_t)elog.convolutions;
         double total = 0.0;
         for (int k = 0; k < 5; ++k) res->kernel_ms[k] = 0.0;
-        for (size_t i = 0; i + per <= elog.used; i += per) {
-            for (size_t k = 0; k + 1 < per; ++k) {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, ev[i + k], ev[i + k + 1]) != hipSuccess) continue;
-                total += ms;
-                if (p->fc) res->kernel_ms[k] += ms;
-            }
+        for (size_t i = 1; i < elog.used; ++i) {
+            const int kind = elog.kinds[i];
+            if (kind < 0) continue;  // opens a span
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev[i - 1], ev[i]) != hipSuccess) continue;
+            total += ms;
+            if (kind < 5) res->kernel_ms[kind] += ms;
         }
         res->conv_ms_total = total;
         res->fused_engine = p->fc ? 1 : 0;
