@@ -220,37 +220,53 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
         const int z = (int)(r / g.Y), y = (int)(r % g.Y);
         const int64_t prow = ((int64_t)(z + g.bz) * g.Yp + (y + g.by)) * g.Xp + g.bx;
         const int64_t irow = r * g.X;
-        for (int x = threadIdx.x; x < g.X; x += 64) {
-            const float h = hu[prow + x];
-            const float v = load_as_f32(image, irow + x);
-            float s1;
-            if (injected) {
-                s1 = injected[irow + x];
-            } else {
-                const float vt = v > 0.0f ? v : 0.0f;
-                // astype(int64) truncation, rlgc.py:619; counts above 2^20 are clamped for
-                // the draw only (bounds the loop; u16 data never reaches it)
-                const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);
-                s1 = (float)binomial_half(n, (uint64_t)(irow + x), iteration, seed);
+        // loads first, four row segments at a time (independent requests in flight), then the arithmetic
+        // in the original element order
+        constexpr int kU = 4;
+        for (int x0 = threadIdx.x; x0 < g.X; x0 += 64 * kU) {
+            float hbuf[kU], vbuf[kU], ibuf[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int xc = min(x0 + 64 * u, g.X - 1);
+                hbuf[u] = hu[prow + xc];
+                vbuf[u] = load_as_f32(image, irow + xc);
+                ibuf[u] = injected ? injected[irow + xc] : 0.0f;
             }
-            const float s2 = v - s1;
-            // kl_div, rlgc.py:401-412, as raw sums (normalisers applied on the host)
-            const float a = h + eps;
-            const float bim = v + eps, b1 = s1 + eps, b2 = s2 + eps;
-            A += a;
-            Bim += bim;
-            B1 += b1;
-            B2 += b2;
-            if (a > 0.0f) {
-                const float la = __logf(a);
-                Tim += a * (la - __logf(bim));
-                T1 += a * (la - __logf(b1));
-                T2 += a * (la - __logf(b2));
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int x = x0 + 64 * u;
+                if (x >= g.X) continue;
+                const float h = hbuf[u];
+                const float v = vbuf[u];
+                float s1;
+                if (injected) {
+                    s1 = ibuf[u];
+                } else {
+                    const float vt = v > 0.0f ? v : 0.0f;
+                    // astype(int64) truncation, rlgc.py:619; counts above 2^20 are clamped for
+                    // the draw only (bounds the loop; u16 data never reaches it)
+                    const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);
+                    s1 = (float)binomial_half(n, (uint64_t)(irow + x), iteration, seed);
+                }
+                const float s2 = v - s1;
+                // kl_div, rlgc.py:401-412, as raw sums (normalisers applied on the host)
+                const float a = h + eps;
+                const float bim = v + eps, b1 = s1 + eps, b2 = s2 + eps;
+                A += a;
+                Bim += bim;
+                B1 += b1;
+                B2 += b2;
+                if (a > 0.0f) {
+                    const float la = __logf(a);
+                    Tim += a * (la - __logf(bim));
+                    T1 += a * (la - __logf(b1));
+                    T2 += a * (la - __logf(b2));
+                }
+                // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668
+                const float den = 0.5f * (h + 1e-12f);
+                r1[prow + x] = rn_div(s1, den);
+                r2[prow + x] = rn_div(s2, den);
             }
-            // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668
-            const float den = 0.5f * (h + 1e-12f);
-            r1[prow + x] = rn_div(s1, den);
-            r2[prow + x] = rn_div(s2, den);
         }
         // fold the row's float32 partials into double every row (bounded error growth)
         dA += A; dBim += Bim; dB1 += B1; dB2 += B2; dTim += Tim; dT1 += T1; dT2 += T2;
