@@ -13,8 +13,9 @@ moving round; then for every readout bit optionally deconvolve (PSF 1 for excita
 
 What differs from the reference, by design:
 
-* One process per GPU.  With ``num_gpus == 1`` (or under ``torch.distributed``, where every
-  rank takes a contiguous share of the rounds / bits, :2137-2141) the work runs in this
+* One process per GPU.  With ``num_gpus == 1``, or under ``torch.distributed`` (whole tiles are
+  dealt to the ranks first; only with fewer tiles than ranks does every rank take a contiguous
+  share of one tile's rounds / bits, the reference's :2137-2141 split), the work runs in this
   process and volumes stay in HBM between deconvolution, clipping and registration - the
   reference pickles the uint16 reference volume into every worker and re-uploads it.
   ``num_gpus > 1`` without a process group spawns one child per GPU like the reference
@@ -375,6 +376,7 @@ class DataRegistration:
         self._verbose = verbose
         self._feature_predictor = feature_predictor
         self._tile_id = None
+        self._tile_parallel = False
 
     # ----------------------------------------------------------------- properties (:1237-1344)
     @property
@@ -494,12 +496,38 @@ class DataRegistration:
                 return
             if start_idx > 0 and self._verbose >= 1:
                 print(time_stamp(), f"Resuming local registration at tile id: {tile_ids[start_idx]}.")
-        for tile_id in tile_ids[start_idx:]:
-            self.tile_id = tile_id
-            self._generate_registrations()
-            self._apply_registration_to_bits()
+        todo = tile_ids[start_idx:]
+        # One process per GPU: whole tiles are dealt to the ranks first (contiguous ranges, no cross-rank
+        # dependency: a round registers against its own tile's round 1); only when there are fewer tiles
+        # than ranks are the rounds / bits of a tile shared out instead (the reference's only mode, :2137).
+        mine, self._tile_parallel = self._tiles_for_this_rank(todo)
+        try:
+            for tile_id in mine:
+                self.tile_id = tile_id
+                self._generate_registrations()
+                self._apply_registration_to_bits()
+        finally:
+            tile_parallel, self._tile_parallel = self._tile_parallel, False
+        if tile_parallel:
+            import torch.distributed as dist
+
+            dist.barrier()
         if self._global_registration:
             self.global_register()
+
+    @staticmethod
+    def _tiles_for_this_rank(tile_ids: list):
+        """(this rank's tiles, tile_parallel).  Under torch.distributed with at least one tile per rank:
+        contiguous ceil-sized ranges like PixelDecoder's tile sharding (PixelDecoder.py:4811-4820)."""
+        if not _dist_ready():
+            return list(tile_ids), False
+        import torch.distributed as dist
+
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if world <= 1 or len(tile_ids) < world:
+            return list(tile_ids), False
+        chunk = (len(tile_ids) + world - 1) // world
+        return list(tile_ids[rank * chunk: min((rank + 1) * chunk, len(tile_ids))]), True
 
     def register_one_tile(self, tile_id) -> None:
         self.tile_id = tile_id
@@ -520,6 +548,8 @@ class DataRegistration:
         this rank's chunk only."""
         if not items:
             return [], False
+        if getattr(self, "_tile_parallel", False):  # this rank owns the whole tile
+            return [list(items)], False
         if (not _dist_ready() and min(int(self._num_gpus), len(items)) > 1
                 and getattr(self._datastore, "in_memory", False)):
             raise RuntimeError("num_gpus > 1 spawns one child process per GPU, whose writes to an in-memory "

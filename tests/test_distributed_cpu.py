@@ -68,6 +68,11 @@ def _worker(rank, world, port, ret):
         shares, distributed = reg._shares(list(store.round_ids[1:]))
         out["rounds"] = (shares, distributed)
         out["bits"] = reg._shares(list(store.bit_ids))
+        out["tiles_dr"] = DR.DataRegistration._tiles_for_this_rank(list(store.tile_ids))
+        out["tiles_dr_few"] = DR.DataRegistration._tiles_for_this_rank(["only"])
+        reg._tile_parallel = True          # a rank that owns whole tiles keeps every round / bit of them
+        out["bits_tile_parallel"] = reg._shares(list(store.bit_ids))
+        reg._tile_parallel = False
         dec = PD.PixelDecoder.__new__(PD.PixelDecoder)
         dec._num_gpus = 4
         out["tiles"] = dec._shard(list(range(5)))
@@ -126,6 +131,10 @@ def test_two_rank_shares_pooled_statistics_and_timing():
     bits = [f"bit{i + 1:03d}" for i in range(16)]
     assert res[0]["bits"] == ([bits[:8]], True) and res[1]["bits"] == ([bits[8:]], True)
     assert res[0]["tiles"] == ([[0, 1, 2]], True) and res[1]["tiles"] == ([[3, 4]], True)
+    tiles = [f"tile{i:04d}" for i in range(5)]
+    assert res[0]["tiles_dr"] == (tiles[:3], True) and res[1]["tiles_dr"] == (tiles[3:], True)
+    assert res[0]["tiles_dr_few"] == (["only"], False) and res[1]["tiles_dr_few"] == (["only"], False)
+    assert res[0]["bits_tile_parallel"] == ([bits], False) and res[1]["bits_tile_parallel"] == ([bits], False)
     pooled = np.concatenate([np.concatenate(res[r]["local"]) for r in range(world)]).astype(np.float32)
     for r in range(world):
         assert res[r]["count"] == pooled.size
