@@ -44,7 +44,6 @@ import numpy as np
 import scipy.fft as sfft
 import scipy.ndimage as sndi
 
-from . import registration_ref
 
 
 @dataclass(frozen=True)
@@ -452,4 +451,4 @@ def estimate_sofima_flow_field_xyz_px(fixed, moving, config=None):
     return total.astype(np.float32, copy=False), md
 
 
-__all__ = [n for n in dir() if not n.startswith("_")] + ["registration_ref"]
+__all__ = [n for n in dir() if not n.startswith("_")]

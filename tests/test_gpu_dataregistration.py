@@ -6,7 +6,6 @@ by excitation wavelength, feature-predictor tables, resume (DataRegistration.py:
 import numpy as np
 import pandas as pd
 import pytest
-import torch
 from scipy.ndimage import gaussian_filter, shift as ndi_shift
 
 from conftest import pkg

@@ -7,7 +7,6 @@ mismatches that per-stage parity tests cannot (DataRegistration.py:1522-1591 -> 
 import numpy as np
 import pandas as pd
 import pytest
-import torch
 from scipy.ndimage import gaussian_filter, shift as ndi_shift
 
 from conftest import pkg

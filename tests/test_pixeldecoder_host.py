@@ -1,6 +1,5 @@
 """CPU: host-side logic of the PixelDecoder mirror (no kernel launches)."""
 
-import json
 
 import numpy as np
 import pandas as pd
