@@ -50,7 +50,7 @@ struct FftConvPlan {
     void *tables = nullptr;  // one device allocation holding all twiddle / pos tables
     size_t lds_x, lds_y, lds_z;
     int rset_x, rset_y, rset_z;  // 1: lean kernels (no radix 16 / 8 stage on that axis)
-    int ythreads, zthreads, xthreads, gx, gy, gz;
+    int ythreads, zthreads, xthreads, gx, gy, gz, dual_rows, dual_threads;
 };
 
 }  // namespace m3d
@@ -61,6 +61,7 @@ struct ConvGeo {
     int Zp, Yp, Xp, Xc, TW, nT, RB, P;
     int lTW, lNB, lP;  // log2 of TW, RB/2, P (all powers of two)
     int GX, GY, GZ;    // transforms one thread carries through a butterfly of each pass
+    int lDR;           // log2 of the rows one block of the dual X inverse pass handles
     int64_t plane;
     m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
     m3d::ConvBox mir;      // mirror != 0: the input is the symmetric extension of this box
@@ -339,10 +340,10 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(const float2 *__restrict
 {
     extern __shared__ float2 lds_id[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int nb = g.RB / 2, N = g.Xp;  // nb rows per block, one packed transform each
+    const int nb = 1 << g.lDR, N = g.Xp;  // nb rows per block, one packed transform each
     const int groups = (g.Yp + nb - 1) / nb;
     const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * nb;
-    const int total = (g.nT << g.lNB) << g.lTW;
+    const int total = (g.nT << g.lDR) << g.lTW;
     constexpr int kU = M3D_KU_XI;
     for (int e0 = tid; e0 < total; e0 += nt * kU) {
         float2 Av[kU], Bv[kU];
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(const float2 *__restrict
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int e = min(e0 + u * nt, total - 1);
-            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lDR);
             const int k = min((kt << g.lTW) + kk, g.Xc - 1);
             p1[u] = ax.pos[k];
             p2[u] = ax.pos[k == 0 ? 0 : N - k];
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(const float2 *__restrict
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
             const int e = e0 + u * nt;
-            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lNB);
+            const int kk = e & (g.TW - 1), bi = (e >> g.lTW) & (nb - 1), kt = e >> (g.lTW + g.lDR);
             const int k = (kt << g.lTW) + kk;
             if (e >= total || k >= g.Xc) continue;
             const float2 A = Av[u], B = Bv[u];
@@ -547,6 +548,7 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
     g.GX = p->gx;
     g.GY = p->gy;
     g.GZ = p->gz;
+    g.lDR = __builtin_ctz((unsigned)p->dual_rows);
     return g;
 }
 
@@ -597,6 +599,8 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->gx = knob("M3D_FFT_GX", 4);
     p->gy = knob("M3D_FFT_GY", 4);
     p->gz = knob("M3D_FFT_GZ", 4);
+    p->dual_rows = knob("M3D_FFT_DUAL_ROWS", 2);
+    p->dual_threads = knob("M3D_FFT_DUAL_T", 256);
     p->ythreads = knob("M3D_FFT_YT", 768);
     p->zthreads = std::max(p->P, knob("M3D_FFT_ZT", 128));
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
@@ -651,8 +655,9 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
     (void)hipFuncSetAttribute((const void *)k_x_forward<0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_forward<1>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1>, attr, (int)p->lds_x);
+    const int lds_dual = (int)((size_t)p->dual_rows * Xp * sizeof(float2));
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0>, attr, lds_dual);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1>, attr, lds_dual);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 1>, attr, (int)p->lds_x);
@@ -760,12 +765,13 @@ int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const floa
         !epilogue->o1 || !epilogue->o2 || !epilogue->red)
         return M3D_ERR_INVALID_ARG;
     const ConvGeo g = geo_of(p);
-    const int nb = p->RB / 2;
-    const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->xthreads);
+    const int nb = p->dual_rows;
+    const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
+    const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
     if (p->rset_x)
-        hipLaunchKernelGGL(k_x_inverse_dual<1>, grid, block, p->lds_x, st, spec1, spec2, g, p->ax, *epilogue);
+        hipLaunchKernelGGL(k_x_inverse_dual<1>, grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     else
-        hipLaunchKernelGGL(k_x_inverse_dual<0>, grid, block, p->lds_x, st, spec1, spec2, g, p->ax, *epilogue);
+        hipLaunchKernelGGL(k_x_inverse_dual<0>, grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
