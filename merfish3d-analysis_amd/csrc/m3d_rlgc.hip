@@ -437,6 +437,22 @@ __global__ void k_fused_finalize(unsigned int *cons, unsigned int *upd, Status *
     arm_fused_reductions(cons, upd);
 }
 
+// order-independent 64-bit fingerprint of the PSF values (position-salted splitmix64 of the bit patterns)
+__global__ void k_psf_hash(const float *__restrict__ psf, int64_t n, unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (unsigned long long)__float_as_uint(psf[i]) ^ ((unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull);
+        x ^= x >> 30;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 27;
+        x *= 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        acc += x;
+    }
+    atomicAdd(out, acc);
+}
+
 // enforce_symmetric_boundary (rlgc.py:230-271): z, then y, then x passes compose to
 // recon[z,y,x] = recon[s(z), s(y), s(x)] with every source inside the core.
 __global__ void k_boundary(float *__restrict__ recon, Geo g)
@@ -512,6 +528,11 @@ struct m3d_rlgc_plan {
     hipEvent_t loop_ev[2] = {nullptr, nullptr};
     m3d::FftConvPlan *fc = nullptr;  // fused in-LDS FFT convolution engine (default)
     void *zeroed_workspace = nullptr;  // spectrum tile padding already cleared in this buffer
+    // OTF and update_norm depend only on the PSF (and the plan's geometry): a tile's bits share one or two
+    // PSFs, so they are kept between runs on the same workspace and reused while the PSF fingerprint matches
+    void *setup_workspace = nullptr;
+    unsigned long long setup_psf_hash = 0;
+    int setup_normalize = -1;
 };
 
 #define M3D_ROCFFT_CHECK(expr)                                   \
@@ -817,25 +838,39 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     };
     int rc;
 
-    // ---- setup: OTF (rlgc.py:578-584)
+    // ---- setup: OTF (rlgc.py:578-584) and update_norm (rlgc.py:587-590), unless this workspace still holds
+    // them for the same PSF
     M3D_HIP_CHECK(hipMemsetAsync(dstat, 0, sizeof(Status), st));
-    M3D_HIP_CHECK(hipMemsetAsync(hu, 0, sizeof(float) * (size_t)g.Np, st));
     const int64_t npsf = (int64_t)p->pz * p->py * p->px;
-    hipLaunchKernelGGL(k_psf_sum, dim3(1), dim3(kBlock), 0, st, psf, npsf, dstat);
-    hipLaunchKernelGGL(k_psf_embed, dim3(grid_for(npsf)), dim3(kBlock), 0, st, psf, hu, p->pz,
-                       p->py, p->px, g, dstat, params->normalize_psf);
-    M3D_KERNEL_CHECK();
-    if (p->fc) {
-        if ((rc = m3d::fftconv_make_otf(p->fc, hu, otf, st))) return rc;
-    } else if ((rc = fft_r2c(hu, otf))) {
-        return rc;
+    unsigned long long *hash_dev = (unsigned long long *)kl_part, psf_hash = 0;
+    M3D_HIP_CHECK(hipMemsetAsync(hash_dev, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_psf_hash, dim3(grid_for(npsf)), dim3(kBlock), 0, st, psf, npsf, hash_dev);
+    M3D_HIP_CHECK(hipMemcpyAsync(&psf_hash, hash_dev, sizeof(psf_hash), hipMemcpyDeviceToHost, st));
+    M3D_HIP_CHECK(hipStreamSynchronize(st));
+    const bool reuse_setup = p->setup_workspace == workspace && p->setup_psf_hash == psf_hash &&
+                             p->setup_normalize == (params->normalize_psf ? 1 : 0) &&
+                             !(getenv("M3D_RLGC_NO_SETUP_CACHE") && atoi(getenv("M3D_RLGC_NO_SETUP_CACHE")));
+    if (!reuse_setup) {
+        p->setup_workspace = nullptr;  // invalid until both volumes are complete
+        M3D_HIP_CHECK(hipMemsetAsync(hu, 0, sizeof(float) * (size_t)g.Np, st));
+        hipLaunchKernelGGL(k_psf_sum, dim3(1), dim3(kBlock), 0, st, psf, npsf, dstat);
+        hipLaunchKernelGGL(k_psf_embed, dim3(grid_for(npsf)), dim3(kBlock), 0, st, psf, hu, p->pz,
+                           p->py, p->px, g, dstat, params->normalize_psf);
+        M3D_KERNEL_CHECK();
+        if (p->fc) {
+            if ((rc = m3d::fftconv_make_otf(p->fc, hu, otf, st))) return rc;
+        } else if ((rc = fft_r2c(hu, otf))) {
+            return rc;
+        }
+        hipLaunchKernelGGL(k_mask, dim3(g_pad), rb, 0, st, hu, g);
+        M3D_KERNEL_CHECK();
+        if ((rc = conv(hu, 1, un, kInCore))) return rc;
+        hipLaunchKernelGGL(k_floor, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, un, 1e-6f, g.Np);
+        M3D_KERNEL_CHECK();
+        p->setup_workspace = workspace;
+        p->setup_psf_hash = psf_hash;
+        p->setup_normalize = params->normalize_psf ? 1 : 0;
     }
-
-    // ---- update_norm = max(conv(mask, otfT), 1e-6) (rlgc.py:587-590)
-    hipLaunchKernelGGL(k_mask, dim3(g_pad), rb, 0, st, hu, g);
-    M3D_KERNEL_CHECK();
-    if ((rc = conv(hu, 1, un, kInCore))) return rc;
-    hipLaunchKernelGGL(k_floor, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, un, 1e-6f, g.Np);
 
     // ---- recon = mean(observed) everywhere (rlgc.py:600-603)
     const int g_sum = grid_for(g.N);

@@ -182,3 +182,29 @@ def test_support_pruned_convolutions_equal_the_full_ones(shape, psf_shape, monke
     assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
     np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=1e-5, atol=1e-8)
     assert _rel_err(out, ref) < 2e-5
+
+
+def test_setup_is_reused_for_the_same_psf_and_rebuilt_for_another(monkeypatch):
+    """OTF / update_norm stay in the plan's workspace between runs (a tile's bits share their PSF): reusing
+    them must give the bits a fresh setup gives, and a different PSF must not pick up stale volumes."""
+    rl = pkg("utils.rlgc")
+    rng = np.random.default_rng(23)
+    shape = (10, 48, 52)
+    imgs = [rng.poisson(rng.gamma(2.0, 60.0, size=shape)).astype(np.uint16) for _ in range(2)]
+    zz, yy, xx = np.meshgrid(*[np.arange(n) - n // 2 for n in (5, 9, 9)], indexing="ij")
+    psf_a = np.exp(-0.5 * ((zz / 1.2) ** 2 + (yy / 1.6) ** 2 + (xx / 1.6) ** 2)).astype(np.float32)
+    psf_b = np.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 2.2) ** 2 + (xx / 2.2) ** 2)).astype(np.float32)
+    monkeypatch.setenv("M3D_RLGC_NO_SETUP_CACHE", "1")
+    fresh = [rl.rlgc(imgs[0], psf_a, release_memory=False, max_iterations=8),
+             rl.rlgc(imgs[1], psf_a, release_memory=False, max_iterations=8),
+             rl.rlgc(imgs[1], psf_b, release_memory=False, max_iterations=8),
+             rl.rlgc(imgs[0], psf_a, release_memory=False, max_iterations=8, normalize_psf=False)]
+    monkeypatch.setenv("M3D_RLGC_NO_SETUP_CACHE", "0")
+    rl.clear_rlgc_caches()
+    cached = [rl.rlgc(imgs[0], psf_a, release_memory=False, max_iterations=8),
+              rl.rlgc(imgs[1], psf_a, release_memory=False, max_iterations=8),       # same PSF: setup reused
+              rl.rlgc(imgs[1], psf_b, release_memory=False, max_iterations=8),       # other PSF: rebuilt
+              rl.rlgc(imgs[0], psf_a, release_memory=False, max_iterations=8, normalize_psf=False)]
+    for a, b in zip(fresh, cached):
+        np.testing.assert_array_equal(a, b)
+    assert not np.array_equal(cached[1], cached[2])
