@@ -80,7 +80,8 @@ __host__ __device__ inline float key_float(unsigned int k)
 }
 
 // dst <- irfftn(rfftn(src) * H) with H = otf (mode 0), conj(otf) (1), |otf|^2 (2);
-// `spec` is a scratch spectrum.  src may equal dst.
+// `spec` is a scratch spectrum.  src may equal dst.  src == nullptr: `spec` already holds the X forward
+// transform of the (full-volume) input, and the convolution starts at its Y pass.
 // With an enabled `log` every kernel's time is attributed to its pass (EventLog::Kind).
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
@@ -99,7 +100,9 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
 // both spectra is one packed complex row (S1 + i S2), one inverse transform returns both real rows and
 // ConvEpilogue::kConsensus runs on them in registers (`a` unused: HT1's numerator is the first result).
 // Neither convolution result reaches HBM.
-int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const float2 *spec2, void *stream,
-                           EventLog *log, const ConvEpilogue *epilogue);
+// `chain_forward`: the consensus input is not stored (o1 unused) but transformed along x on the spot;
+// its half-spectrum rows replace spec1, ready for fftconv_conv(src = nullptr, spec = spec1, ...).
+int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *spec2, void *stream,
+                           EventLog *log, const ConvEpilogue *epilogue, bool chain_forward = false);
 
 }  // namespace m3d

@@ -293,7 +293,10 @@ __global__ __launch_bounds__(512) void k_x_inverse(const float2 *__restrict__ sp
 }
 
 // ---------------------------------------------------------------- dual X inverse (two results, one pass)
-__device__ __forceinline__ void dual_consensus_epilogue(const float2 *lds, const ConvGeo &g, const m3d::ConvEpilogue &ep,
+// CHAIN: the product is not stored but left in LDS row 0 as (row y0, row y0 + 1) - the packed input of
+// the next convolution's X forward transform.
+template <bool CHAIN>
+__device__ __forceinline__ void dual_consensus_epilogue(float2 *lds, const ConvGeo &g, const m3d::ConvEpilogue &ep,
                                                         int z, int y0, int nb, int N, int tid, int nt)
 {
 #pragma clang fp contract(off)
@@ -316,7 +319,15 @@ __device__ __forceinline__ void dual_consensus_epilogue(const float2 *lds, const
                 if (n >= N) continue;
                 const float2 v = lds[bi * N + n];  // (HTratio1 raw, HTratio2 raw)
                 const float h1 = v.x / un[u], h2 = v.y / un[u];
-                ep.o1[row + n] = (h1 - 1.0f) * (h2 - 1.0f);
+                const float prod = (h1 - 1.0f) * (h2 - 1.0f);
+                if constexpr (CHAIN) {
+                    if (bi == 0)
+                        lds[n] = make_float2(prod, 0.0f);
+                    else
+                        lds[n].y = prod;
+                } else {
+                    ep.o1[row + n] = prod;
+                }
                 const float hs = h1 + h2;
                 mn = fminf(mn, hs);
                 mx = fmaxf(mx, hs);
@@ -333,8 +344,11 @@ __device__ __forceinline__ void dual_consensus_epilogue(const float2 *lds, const
 }
 
 // Full output box only (the consensus input is needed on the whole padded volume).
-template <int RSET>
-__global__ __launch_bounds__(512) void k_x_inverse_dual(const float2 *__restrict__ spec1,
+// CHAIN (two rows per block): the consensus input goes straight into the X forward transform of the
+// convolution that consumes it, and its two half-spectrum rows overwrite this block's rows of spec1 -
+// the product never exists in HBM either.
+template <int RSET, bool CHAIN>
+__global__ __launch_bounds__(512) void k_x_inverse_dual(float2 *__restrict__ spec1,
                                                         const float2 *__restrict__ spec2, ConvGeo g, AxisPlan ax,
                                                         m3d::ConvEpilogue ep)
 {
@@ -372,7 +386,32 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(const float2 *__restrict
     }
     __syncthreads();
     lds_fft<true, RSET>(lds_id, ax, 1, nb, N, tid, nt, g.GX);
-    dual_consensus_epilogue(lds_id, g, ep, z, y0, nb, N, tid, nt);
+    dual_consensus_epilogue<CHAIN>(lds_id, g, ep, z, y0, nb, N, tid, nt);
+    if constexpr (CHAIN) {
+        __syncthreads();
+        lds_fft<false, RSET>(lds_id, ax, 1, 1, N, tid, nt, g.GX);
+        // Hermitian split of the packed pair, as in k_x_forward
+        constexpr int kS = 3;
+        const int tot = g.nT << g.lTW;
+        for (int e0 = tid; e0 < tot; e0 += nt * kS) {
+            int p1[kS], p2[kS];
+#pragma unroll
+            for (int u = 0; u < kS; ++u) {
+                const int k = min(e0 + u * nt, g.Xc - 1);
+                p1[u] = ax.pos[k];
+                p2[u] = ax.pos[k == 0 ? 0 : N - k];
+            }
+#pragma unroll
+            for (int u = 0; u < kS; ++u) {
+                const int k = e0 + u * nt;
+                if (k >= g.Xc) continue;
+                const float2 c1 = lds_id[p1[u]], c2 = lds_id[p2[u]];
+                spec1[spec_index(g, z, y0, k)] = make_float2(0.5f * (c1.x + c2.x), 0.5f * (c1.y - c2.y));
+                if (y0 + 1 < g.Yp)
+                    spec1[spec_index(g, z, y0 + 1, k)] = make_float2(0.5f * (c1.y + c2.y), 0.5f * (c2.x - c1.x));
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- Y pass (in place)
@@ -656,8 +695,10 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_x_forward<0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_forward<1>, attr, (int)p->lds_x);
     const int lds_dual = (int)((size_t)p->dual_rows * Xp * sizeof(float2));
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0>, attr, lds_dual);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1>, attr, lds_dual);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0, false>, attr, lds_dual);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1, false>, attr, lds_dual);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0, true>, attr, lds_dual);
+    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1, true>, attr, lds_dual);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 1>, attr, (int)p->lds_x);
@@ -696,11 +737,13 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
     const ConvGeo g = geo_of(p, in_box, nullptr, mirror_box);
     const int groups = row_groups(p, g.in);
     if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
-    if (p->rset_x)
-        hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
-    else
-        hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
-    if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
+    if (src) {  // src == nullptr: the half-spectrum rows are already in `spec` (chained from another pass)
+        if (p->rset_x)
+            hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
+        else
+            hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
+        if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
+    }
     if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
     else
@@ -757,21 +800,27 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     return M3D_OK;
 }
 
-int fftconv_dual_consensus(const FftConvPlan *p, const float2 *spec1, const float2 *spec2, void *stream,
-                           EventLog *log, const ConvEpilogue *epilogue)
+int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *spec2, void *stream,
+                           EventLog *log, const ConvEpilogue *epilogue, bool chain_forward)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!spec1 || !spec2 || !epilogue || epilogue->kind != ConvEpilogue::kConsensus || !epilogue->b ||
-        !epilogue->o1 || !epilogue->o2 || !epilogue->red)
+        (!chain_forward && !epilogue->o1) || !epilogue->o2 || !epilogue->red ||
+        (chain_forward && p->dual_rows != 2))
         return M3D_ERR_INVALID_ARG;
     const ConvGeo g = geo_of(p);
     const int nb = p->dual_rows;
     const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
     const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
-    if (p->rset_x)
-        hipLaunchKernelGGL(k_x_inverse_dual<1>, grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+    if (chain_forward) {
+        if (p->rset_x)
+            hipLaunchKernelGGL((k_x_inverse_dual<1, true>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+        else
+            hipLaunchKernelGGL((k_x_inverse_dual<0, true>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+    } else if (p->rset_x)
+        hipLaunchKernelGGL((k_x_inverse_dual<1, false>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     else
-        hipLaunchKernelGGL(k_x_inverse_dual<0>, grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+        hipLaunchKernelGGL((k_x_inverse_dual<0, false>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;

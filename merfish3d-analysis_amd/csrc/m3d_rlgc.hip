@@ -920,11 +920,13 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             elog.convolutions += 2;
             if ((rc2 = m3d::fftconv_to_rows(p->fc, r1, otf, 1, cbuf, st, &elog, in, nullptr, nullptr))) return rc2;
             if ((rc2 = m3d::fftconv_to_rows(p->fc, r2, otf, 1, cbuf2, st, &elog, in, nullptr, nullptr))) return rc2;
+            // ... and the consensus input goes straight into the X forward transform of its own convolution
+            const bool chain = !(getenv("M3D_RLGC_NO_CHAIN") && atoi(getenv("M3D_RLGC_NO_CHAIN")));
             const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, nullptr, un, hu, w1, cons_red, core};
-            if ((rc2 = m3d::fftconv_dual_consensus(p->fc, cbuf, cbuf2, st, &elog, &e1))) return rc2;
+            if ((rc2 = m3d::fftconv_dual_consensus(p->fc, cbuf, cbuf2, st, &elog, &e1, chain))) return rc2;
             const m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr,
                                           upd_red, core};
-            if ((rc2 = conv(hu, 2, w2, kOutCore, &e2))) return rc2;
+            if ((rc2 = conv(chain ? nullptr : hu, 2, w2, kOutCore, &e2))) return rc2;
             hipLaunchKernelGGL(k_fused_finalize, dim3(1), dim3(64), 0, st, cons_red, upd_red, dstat);
             M3D_KERNEL_CHECK();
             return M3D_OK;
