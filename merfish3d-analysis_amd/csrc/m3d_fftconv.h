@@ -86,16 +86,19 @@ __host__ __device__ inline float key_float(unsigned int k)
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                  const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr,
-                 const ConvEpilogue *epilogue = nullptr);
+                 const ConvEpilogue *epilogue = nullptr, float2 *spec_alt = nullptr);
 // `mirror_box` (exclusive with in_box): src is only valid inside the box and stands for its
 // symmetric extension to the whole volume (np.pad mode="symmetric", rlgc.py:203-271) - the
-// X pass gathers through the index map instead of reading a materialised pad region.
+// X pass gathers through the index map instead of reading a materialised pad region.  With a second
+// scratch spectrum `spec_alt` only the box's own rows are transformed along x (mirrored rows have the
+// same transform) and the Y pass assembles every plane from the core plane it mirrors.
 
 // fft_conv without its X inverse pass: afterwards `spec` holds the half spectrum along x of every
 // (z, y) row of the result (rows of `out_box` only).
 int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                     void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
-                    const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr);
+                    const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr,
+                    float2 *spec_alt = nullptr, float2 **rows = nullptr);  // *rows: the buffer that holds them
 // The X inverse pass shared by two such results that meet in the consensus arithmetic: the same row of
 // both spectra is one packed complex row (S1 + i S2), one inverse transform returns both real rows and
 // ConvEpilogue::kConsensus runs on them in registers (`a` unused: HT1's numerator is the first result).

@@ -94,10 +94,11 @@ __global__ __launch_bounds__(512) void k_x_forward(const float *__restrict__ src
     for (int bi = 0; bi < nb; ++bi) {
         const int ya = y0 + 2 * bi, yb = ya + 1;
         const bool va = ya >= g.in.y0 && ya < y_hi, vb = yb >= g.in.y0 && yb < y_hi;
-        // source rows: themselves, or their mirror images inside the box (symmetric extension)
-        const int zs = g.mirror ? sym_src(z, g.mir.z0, g.mir.nz) : z;
-        const int yas = g.mirror ? sym_src(min(ya, g.Yp - 1), g.mir.y0, g.mir.ny) : (va ? ya : g.in.y0);
-        const int ybs = g.mirror ? sym_src(min(yb, g.Yp - 1), g.mir.y0, g.mir.ny) : (vb ? yb : g.in.y0);
+        // source rows: themselves, or (mirror == 1) their mirror images inside the box (symmetric extension);
+        // mirror == 2 transforms the box's own rows only, extended symmetrically along x
+        const int zs = g.mirror == 1 ? sym_src(z, g.mir.z0, g.mir.nz) : z;
+        const int yas = g.mirror == 1 ? sym_src(min(ya, g.Yp - 1), g.mir.y0, g.mir.ny) : (va ? ya : g.in.y0);
+        const int ybs = g.mirror == 1 ? sym_src(min(yb, g.Yp - 1), g.mir.y0, g.mir.ny) : (vb ? yb : g.in.y0);
         const float *ra = src + ((int64_t)zs * g.Yp + yas) * N;
         const float *rbp = src + ((int64_t)zs * g.Yp + ybs) * N;
         for (int n0 = tid; n0 < N; n0 += nt * kUL) {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(512) void k_x_forward(const float *__restrict__ src
 #pragma unroll
             for (int u = 0; u < kUL; ++u) {
                 const int n = n0 + u * nt;
-                const bool vx = n >= g.in.x0 && n < x_hi;
+                const bool vx = g.mirror || (n >= g.in.x0 && n < x_hi);
                 if (n < N) lds_fx[bi * N + n] = make_float2(va && vx ? a[u] : 0.0f, vb && vx ? b[u] : 0.0f);
             }
         }
@@ -454,6 +455,46 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
     }
 }
 
+// Y forward pass of a volume given by its core rows only (symmetric extension along y and z): plane z is
+// built from the rows of core plane sym_src(z) - X transforms of mirrored rows are copies, so the X pass
+// only transforms the core.  Out of place (several planes read the same core plane).
+template <int RSET>
+__global__ __launch_bounds__(1024) void k_y_forward_mirror(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                          ConvGeo g, AxisPlan ay)
+{
+    extern __shared__ float2 lds_ym[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int z = blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
+    const int zs = sym_src(z, g.mir.z0, g.mir.nz);
+    const float2 *stile = src + ((int64_t)zs * g.nT + kt) * g.Yp * g.TW;
+    float2 *dtile = dst + ((int64_t)z * g.nT + kt) * g.Yp * g.TW;
+    const int n = g.Yp * g.TW;
+    const int lo = g.mir.y0 * g.TW, hi = (g.mir.y0 + g.mir.ny) * g.TW;
+    {   // TW is even on this path: 16-byte copies
+        const float4 *t4 = (const float4 *)stile;
+        float4 *l4 = (float4 *)lds_ym;
+        constexpr int kU = M3D_KU_Y;
+        for (int i0 = lo / 2 + tid; i0 < hi / 2; i0 += nt * kU) {
+            float4 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) v[u] = t4[min(i0 + u * nt, hi / 2 - 1)];
+#pragma unroll
+            for (int u = 0; u < kU; ++u)
+                if (i0 + u * nt < hi / 2) l4[i0 + u * nt] = v[u];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) {
+        if (i >= lo && i < hi) continue;
+        const int y = i >> g.lTW, kk = i & (g.TW - 1);
+        lds_ym[i] = lds_ym[(sym_src(y, g.mir.y0, g.mir.ny) << g.lTW) + kk];
+    }
+    __syncthreads();
+    lds_fft<false, RSET>(lds_ym, ay, g.TW, g.TW, 1, tid, nt, g.GY);
+    float4 *t4 = (float4 *)dtile, *l4 = (float4 *)lds_ym;
+    for (int i = tid; i < n / 2; i += nt) t4[i] = l4[i];
+}
+
 // ---------------------------------------------------------------- Z pass
 // mode 0: S*H  1: S*conj(H)  2: S*|H|^2  (then * scale), -1: forward only (OTF construction)
 template <int RSET>
@@ -571,7 +612,7 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
     g.in = in ? *in : full;
     g.out = out ? *out : full;
     g.mir = mirror ? *mirror : full;
-    g.mirror = mirror ? 1 : 0;
+    g.mirror = mirror ? 1 : 0;  // callers set 2 for the rows-of-the-box-only variant
     g.Zp = p->Zp;
     g.Yp = p->Yp;
     g.Xp = p->Xp;
@@ -705,6 +746,8 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 1>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 2>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 2>, attr, (int)p->lds_x);
+    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<0>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<1>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
@@ -732,8 +775,27 @@ static int row_groups(const FftConvPlan *p, const m3d::ConvBox &b)
 
 static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
                              EventLog *log = nullptr, const ConvBox *in_box = nullptr,
-                             const ConvBox *mirror_box = nullptr)
+                             const ConvBox *mirror_box = nullptr, float2 *spec_alt = nullptr)
 {
+    if (src && mirror_box && spec_alt && p->TW % 2 == 0) {
+        // symmetric extension given by its core: X transforms of the core rows only, the Y pass builds
+        // every plane from the core plane it mirrors (out of place: spec -> spec_alt)
+        ConvGeo g = geo_of(p, mirror_box, nullptr, mirror_box);
+        g.mirror = 2;
+        const int groups = row_groups(p, g.in);
+        if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
+        if (p->rset_x)
+            hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
+        else
+            hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
+        if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
+        if (p->rset_y)
+            hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
+        else
+            hipLaunchKernelGGL(k_y_forward_mirror<0>, dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
+        M3D_KERNEL_CHECK();
+        return M3D_OK;
+    }
     const ConvGeo g = geo_of(p, in_box, nullptr, mirror_box);
     const int groups = row_groups(p, g.in);
     if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
@@ -775,13 +837,15 @@ static bool box_ok(const FftConvPlan *p, const ConvBox *b)
 
 int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                     void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
-                    const ConvBox *mirror_box)
+                    const ConvBox *mirror_box, float2 *spec_alt, float2 **rows)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!box_ok(p, in_box) || !box_ok(p, out_box) || !box_ok(p, mirror_box) || (in_box && mirror_box))
         return M3D_ERR_INVALID_ARG;
-    int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box);
+    int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box, spec_alt);
     if (rc) return rc;
+    if (src && mirror_box && spec_alt && p->TW % 2 == 0) spec = spec_alt;  // the mirrored Y pass wrote there
+    if (rows) *rows = spec;
     if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
     const ConvGeo g = geo_of(p, in_box, out_box);
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
@@ -828,10 +892,10 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
 
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
-                 const ConvBox *mirror_box, const ConvEpilogue *epilogue)
+                 const ConvBox *mirror_box, const ConvEpilogue *epilogue, float2 *spec_alt)
 {
     hipStream_t st = (hipStream_t)stream;
-    int rc = fftconv_to_rows(p, src, otf, mode, spec, stream, log, in_box, out_box, mirror_box);
+    int rc = fftconv_to_rows(p, src, otf, mode, spec, stream, log, in_box, out_box, mirror_box, spec_alt, &spec);
     if (rc) return rc;
     const ConvGeo g = geo_of(p, in_box, out_box);
     const int groups = row_groups(p, g.out);

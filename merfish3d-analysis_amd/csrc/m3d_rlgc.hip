@@ -826,7 +826,8 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog,
                                      prune && (support & kInCore) ? &core : nullptr,
                                      prune && (support & kOutCore) ? &core : nullptr,
-                                     prune && (support & kMirrorIn) ? &core : nullptr, epi);
+                                     prune && (support & kMirrorIn) ? &core : nullptr, epi,
+                                     fused_tail && (support & kMirrorIn) ? (float2 *)w2 : nullptr);
         int rc = stamp(m3d::EventLog::kStart);
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
