@@ -34,10 +34,10 @@ def load(path):
 
 
 def per_call_totals(path, scale):
-    """Bytes per m3d_rlgc_run call (k_psf_sum opens each call)."""
+    """Bytes per m3d_rlgc_run call (k_psf_hash opens each call)."""
     totals = []
     for _i, name, v in rows(path):
-        if name.startswith("k_psf_sum"):
+        if name.startswith("k_psf_hash"):
             totals.append(0.0)
         if totals:
             totals[-1] += scale * v
@@ -58,7 +58,9 @@ def main():
             "hbm_bytes_corrected_mean": 2.0 * sum(f) / len(f) + sum(w) / len(w),
             "in_padded_f32_volumes": round((2.0 * sum(f) / len(f) + sum(w) / len(w)) / vol, 3),
         }
-    n_conv = sum(len(v) for k, v in fetch.items() if k.startswith("k_x_inverse"))
+    # one Z pass per convolution (the two ratio convolutions share their X inverse pass); the OTF's
+    # forward-only Z pass of the first call is counted too
+    n_conv = sum(len(v) for k, v in fetch.items() if k.startswith("k_z_conv"))
     total = 0.0
     for k, v in kernels.items():
         if k.startswith(CONV):
