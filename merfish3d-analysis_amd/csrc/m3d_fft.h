@@ -278,7 +278,7 @@ __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estrid
     }
 }
 
-// RSET selects which butterflies a kernel is compiled with: 0 = all, 1 = lean {9,4,3,2}
+// RSET selects which butterflies a kernel is compiled with: 0 = all, 1 = lean {9,4,3,2}, 2 = lean + radix 8
 // (registers: the radix-16 butterfly alone costs ~40 VGPRs more than radix 9).
 template <bool INV, int RSET>
 __device__ __forceinline__ void lds_stage_r(int r, float2 *data, int n, int M, int estride, int batch,
@@ -294,7 +294,7 @@ __device__ __forceinline__ void lds_stage_r(int r, float2 *data, int n, int M, i
             break;
         case 9: lds_stage<9, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
         case 8:
-            if constexpr (RSET == 0) lds_stage<8, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax);
+            if constexpr (RSET == 0 || RSET == 2) lds_stage<8, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax);
             break;
         case 4: lds_stage<4, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;
         case 3: lds_stage<3, INV>(data, n, M, estride, batch, bstride, tw, tid, nthreads, gmax); break;

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
         if (live && z >= g.out.z0 && z < g.out.z0 + g.out.nz) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
 }
 
-bool factor_23(int n, int *radix, int *nstages)
+bool factor_23(int n, int *radix, int *nstages, bool z_axis = false)
 {
     int c3 = 0, c2 = 0, m = n;
     while (m % 3 == 0) {
@@ -586,6 +586,16 @@ bool factor_23(int n, int *radix, int *nstages)
     for (int i = 0; i < c3 / 2; ++i) radix[s++] = 9;
     if (c3 % 2) radix[s++] = 3;
     static const bool small_pow2 = getenv("M3D_FFT_BIG_RADIX") == nullptr;  // 4,4,4,2 beat 16,8 (VGPRs)
+    // Z axis (short power-of-two transforms, k_z_conv<2>): as few radix-8 stages as bring the stage count
+    // down to ceil(log2(n) / 3) - 128 = 8 * 4 * 4 has three barriers per transform instead of four
+    // (measured 1.93 -> 1.71 ms); M3D_FFT_Z_RADIX4=1 keeps 4, 4, 4, 2.
+    if (z_axis && small_pow2 && getenv("M3D_FFT_Z_RADIX4") == nullptr) {
+        const int best = (c2 + 2) / 3;
+        int n8 = 0;
+        while ((c2 - 3 * n8 + 1) / 2 + n8 > best) ++n8;
+        for (int i = 0; i < n8; ++i) radix[s++] = 8;
+        c2 -= 3 * n8;
+    }
     while (c2 >= 4 && !small_pow2) {
         radix[s++] = 16;
         c2 -= 4;
@@ -645,7 +655,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->Xp = Xp;
     p->Xc = Xp / 2 + 1;
     if (!factor_23(Xp, p->ax.radix, &p->ax.nstages) || !factor_23(Yp, p->ay.radix, &p->ay.nstages) ||
-        !factor_23(Zp, p->az.radix, &p->az.nstages)) {
+        !factor_23(Zp, p->az.radix, &p->az.nstages, true)) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
     }
@@ -653,9 +663,12 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->ay.n = Yp;
     p->az.n = Zp;
     auto lean = [](const AxisPlan &a) {
-        for (int s = 0; s < a.nstages; ++s)
-            if (a.radix[s] == 16 || a.radix[s] == 8) return 0;
-        return 1;
+        int r = 1;
+        for (int s = 0; s < a.nstages; ++s) {
+            if (a.radix[s] == 16) return 0;
+            if (a.radix[s] == 8) r = 2;
+        }
+        return r;
     };
     p->rset_x = lean(p->ax);
     p->rset_y = lean(p->ay);
@@ -752,6 +765,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<true, 1>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_z_conv<2>, attr, (int)p->lds_z);
     (void)hipFuncSetAttribute((const void *)k_z_conv<0>, attr, (int)p->lds_z);
     (void)hipFuncSetAttribute((const void *)k_z_conv<1>, attr, (int)p->lds_z);
     *out = p;
@@ -821,7 +835,9 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
     if (rc) return rc;
     const ConvGeo g = geo_of(p);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
-    if (p->rset_z)
+    if (p->rset_z == 2)
+        hipLaunchKernelGGL(k_z_conv<2>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
+    else if (p->rset_z)
         hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
     else
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
@@ -850,7 +866,9 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     const ConvGeo g = geo_of(p, in_box, out_box);
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
-    if (p->rset_z)
+    if (p->rset_z == 2)
+        hipLaunchKernelGGL(k_z_conv<2>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    else if (p->rset_z)
         hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
     else
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
