@@ -3,9 +3,11 @@
 ORACLE / TEST INFRASTRUCTURE ONLY - see ``oracle/__init__.py``.
 
 The reference delegates the arithmetic to cuCIM / scikit-image (``label``,
-``remove_small_objects``, ``regionprops_table``) - neither is installed here and no
-reference test exercises ``_extract_barcodes``, so this module restates the published
-scikit-image semantics and is **parity unpinned** (SURVEY.md 8c).  What it fixes:
+``remove_small_objects``, ``regionprops_table``).  No reference test exercises
+``_extract_barcodes``; the library arithmetic restated here is pinned bit for bit by
+``tests/golden/skimage_regionprops.npz`` (real scikit-image 0.18.3,
+``tests/golden/make_golden_skimage.py``), the table post-processing is a restatement.
+What it fixes:
 
 * ``label(background=-1, connectivity=3)``: 26-connected regions of *equal* codeword id,
   numbered in raster order of each region's first voxel; 2-D mode labels each plane with

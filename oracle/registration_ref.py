@@ -87,17 +87,23 @@ def _disambiguate_shift(reference_image, moving_image, shift):
                      for sl, p, n in zip(max_slice, positive_shift, negative_shift)])
 
 
-def phase_cross_correlation(reference_image, moving_image, upsample_factor=10, disambiguate=True):
+def phase_cross_correlation(reference_image, moving_image, upsample_factor=10, disambiguate=True,
+                            normalization="phase"):
     """Shift that registers ``moving`` onto ``reference`` (scikit-image semantics, real space,
-    normalization="phase").  float32 images -> complex64 spectra like the GPU libraries."""
+    normalization="phase" as the reference calls it).  float32 images -> complex64 spectra like the GPU
+    libraries.  ``normalization=None, disambiguate=False`` is the scikit-image 0.18 behaviour, which
+    ``tests/golden/skimage_phase_correlation.npz`` (real scikit-image 0.18.3) pins."""
     reference_image = np.asarray(reference_image, dtype=np.float32)
     moving_image = np.asarray(moving_image, dtype=np.float32)
     src_freq = sfft.fftn(reference_image)
     target_freq = sfft.fftn(moving_image)
     shape = src_freq.shape
     image_product = src_freq * target_freq.conj()
-    eps = np.finfo(image_product.real.dtype).eps
-    image_product /= np.maximum(np.abs(image_product), 100 * eps)
+    if normalization == "phase":
+        eps = np.finfo(image_product.real.dtype).eps
+        image_product /= np.maximum(np.abs(image_product), 100 * eps)
+    elif normalization is not None:
+        raise ValueError("normalization must be 'phase' or None")
     cross_correlation = sfft.ifftn(image_product)
     maxima = np.unravel_index(np.argmax(np.abs(cross_correlation)), cross_correlation.shape)
     midpoint = np.array([np.fix(n / 2) for n in shape])

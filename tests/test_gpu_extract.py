@@ -60,6 +60,41 @@ def test_region_table_matches_oracle_on_golden_decode(golden):
     assert diff.max() <= 1e-3
 
 
+def test_component_table_matches_scikit_image_golden(golden):
+    """The HIP labelling and per-component sums against the real scikit-image 0.18.3
+    (tests/golden/make_golden_skimage.py): labels bit for bit, float16 means to the double-rounding bound."""
+    kernels = pkg("kernels")
+    g, s = golden("decode_pixels_16"), golden("skimage_regionprops")
+    for is3d, want in ((True, s["labels3"]), (False, s["labels2"])):
+        table = kernels.connected_component_table(_t(g["decoded"]), _t(g["scaled"]), _t(g["magnitude"]),
+                                                  _t(g["distance"]), is_3d=is3d)
+        rank = {int(r): i + 1 for i, r in enumerate(table["root"])}
+        roots = table["labels"].cpu().numpy().ravel()
+        got = np.array([rank[int(r)] if r >= 0 else 0 for r in roots]).reshape(want.shape)
+        assert np.array_equal(got, want)
+        if not is3d:
+            continue
+        sums = table["sums"]
+        keep = s["label"] - 1  # remove_small_objects(min_size=3) survivors, by scikit-image label
+        area = sums[keep, 0]
+        np.testing.assert_array_equal(area, s["area"])
+        np.testing.assert_allclose(sums[keep, 1:4] / area[:, None], s["centroid"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(table["min_distance"][keep].astype(np.float32), s["distance_min"])
+        means = (sums[keep, kernels.SUM_COLS:].astype(np.float32) / area.astype(np.float32)[:, None]).astype(np.float16)
+        assert np.abs(means.astype(np.float64) - s["intensity_mean"]).max() <= 1e-3
+        assert np.mean(means.astype(np.float64) == s["intensity_mean"]) > 0.99
+        z, y, x = (sums[keep, 1 + k] / area for k in range(3))
+        mzz, myy, mxx = sums[keep, 4] / area - z * z, sums[keep, 5] / area - y * y, sums[keep, 6] / area - x * x
+        mzy, mzx, myx = sums[keep, 7] / area - z * y, sums[keep, 8] / area - z * x, sums[keep, 9] / area - y * x
+        T = np.zeros((len(keep), 3, 3))
+        T[:, 0, 0], T[:, 1, 1], T[:, 2, 2] = myy + mxx, mzz + mxx, mzz + myy
+        T[:, 0, 1] = T[:, 1, 0] = -mzy
+        T[:, 0, 2] = T[:, 2, 0] = -mzx
+        T[:, 1, 2] = T[:, 2, 1] = -myx
+        eig = np.clip(np.linalg.eigvalsh(T), 0, None)[:, ::-1]
+        np.testing.assert_allclose(eig, s["inertia_tensor_eigvals"], rtol=1e-9, atol=1e-9)
+
+
 def _decoder_for(golden_npz, lowpass, minimum_pixels=3):
     PD = pkg("PixelDecoder")
     g = golden_npz

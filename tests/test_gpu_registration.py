@@ -87,3 +87,18 @@ def test_register_pair_to_fixed_residual_uses_valid_lateral_overlap():
     np.testing.assert_allclose(np.asarray(Tu[:3, 3]) / np.asarray(spacing), (1.0, 8.0, -7.0), atol=0.35)
     with pytest.raises(ValueError):
         mv.register_pair_to_fixed(fixed, moving[:, :10], spacing_zyx_um=spacing)
+
+
+def test_phase_cross_correlation_on_the_scikit_image_fixture(golden):
+    """The images of tests/golden/skimage_phase_correlation.npz (real scikit-image 0.18.3 answers):
+    the HIP path equals the oracle's phase-normalised variant and stays within one upsampling step
+    of scikit-image's un-normalised answer."""
+    mv = pkg("utils.multiview_registration")
+    s = golden("skimage_phase_correlation")
+    for i in range(4):
+        ref, mov = s[f"ref_{i}"], s[f"mov_{i}"]
+        got = mv.phase_cross_correlation(torch.from_numpy(ref).to(DEV), torch.from_numpy(mov).to(DEV),
+                                         upsample_factor=10, disambiguate=False)
+        want = R.phase_cross_correlation(ref, mov, upsample_factor=10, disambiguate=False)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)
+        assert np.abs(got - s[f"shift_{i}_up10"]).max() <= 0.1 + 1e-5

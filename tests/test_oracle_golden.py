@@ -151,3 +151,54 @@ def test_ccl_oracle_agrees_with_scipy_labelling(is3d):
     first = np.full(n + 1, dec.size, dtype=np.int64)
     np.minimum.at(first, labels.ravel(), np.arange(dec.size))
     assert (np.diff(first[1:]) > 0).all()
+
+
+def test_labels_and_region_table_match_scikit_image_golden(golden):
+    """``label`` / ``remove_small_objects`` / ``regionprops_table`` as computed by the real
+    scikit-image 0.18.3 (tests/golden/make_golden_skimage.py) on the reference-run decode fixture."""
+    from oracle import ccl_ref
+
+    s = golden("skimage_regionprops")
+    g = golden("decode_pixels_16")
+    lab3, n3 = ccl_ref.label_equal(g["decoded"], is_3d=True)
+    np.testing.assert_array_equal(lab3, s["labels3"])
+    lab2, n2 = ccl_ref.label_equal(g["decoded"], is_3d=False)
+    np.testing.assert_array_equal(lab2, s["labels2"])
+    kept = lab3.copy()
+    counts = np.bincount(kept.ravel())
+    kept[np.isin(kept, np.nonzero(counts <= 2)[0])] = 0
+    np.testing.assert_array_equal(kept, s["kept"])
+    df = ccl_ref.region_table(kept, np.moveaxis(g["scaled"], 0, -1), g["magnitude"], g["distance"])
+    np.testing.assert_array_equal(df["label"].to_numpy(), s["label"])
+    np.testing.assert_array_equal(df["area"].to_numpy(), s["area"])
+    cen = df[[f"centroid-{k}" for k in range(3)]].to_numpy()
+    np.testing.assert_allclose(cen, s["centroid"], rtol=0, atol=1e-12)
+    B = g["scaled"].shape[0]
+    im = df[[f"intensity_mean-{k}" for k in range(B)]].to_numpy().astype(np.float64)
+    np.testing.assert_array_equal(im, s["intensity_mean"])          # float16 means, bit for bit
+    ev = df[[f"inertia_tensor_eigvals-{k}" for k in range(3)]].to_numpy()
+    np.testing.assert_allclose(ev, s["inertia_tensor_eigvals"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_array_equal(df["magnitude_mean"].to_numpy().astype(np.float64), s["magnitude_mean"])
+    np.testing.assert_array_equal(df["distance_min"].to_numpy().astype(np.float32), s["distance_min"])
+
+
+def test_phase_correlation_matches_scikit_image_golden(golden):
+    """FFT sign conventions, peak -> shift wrap and the upsampled-DFT refinement against the real
+    scikit-image 0.18.3 (its un-normalised correlation; ``normalization="phase"`` and ``disambiguate``
+    came later and stay restated from the published source)."""
+    from oracle import registration_ref
+
+    s = golden("skimage_phase_correlation")
+    for i in range(4):
+        ref, mov = s[f"ref_{i}"], s[f"mov_{i}"]
+        for up in (1, 10):
+            got = registration_ref.phase_cross_correlation(ref, mov, upsample_factor=up, disambiguate=False,
+                                                           normalization=None)
+            np.testing.assert_allclose(got, s[f"shift_{i}_up{up}"], rtol=0, atol=1e-6)
+        # the variant the reference calls agrees on these well-posed cases (one upsampling step at most)
+        # (the test images are circular shifts, so the disambiguated wrap is arbitrary: compare modulo the shape)
+        full = registration_ref.phase_cross_correlation(ref, mov, upsample_factor=10, disambiguate=True)
+        n = np.asarray(ref.shape, dtype=np.float64)
+        wrap = lambda d: (d + n / 2) % n - n / 2
+        assert np.abs(wrap(full - s[f"shift_{i}_up10"])).max() <= 0.1 + 1e-5
+        assert np.abs(wrap(full + s[f"true_{i}"])).max() <= 0.2 + 1e-5
