@@ -72,10 +72,26 @@ class RLGCResult(ctypes.Structure):
     ]
 
 
+class BloscHeader(ctypes.Structure):
+    _fields_ = [
+        ("nbytes", ctypes.c_uint32), ("blocksize", ctypes.c_uint32), ("cbytes", ctypes.c_uint32),
+        ("typesize", c_int32), ("shuffle", c_int32), ("codec", c_int32), ("memcpyed", c_int32),
+        ("split", c_int32), ("nblocks", c_int32),
+    ]
+
+
+class IOStats(ctypes.Structure):
+    _fields_ = [
+        ("seconds_total", ctypes.c_double), ("seconds_entropy", ctypes.c_double),
+        ("file_bytes", c_int64), ("raw_bytes", c_int64), ("chunks", c_int32), ("chunks_missing", c_int32),
+    ]
+
+
 STOP_REASONS = {0: "", 1: "restore_previous_recon", 2: "limit", 3: "max_delta", 4: "max_iterations"}
 
 _I3 = c_int32 * 3
 _F3 = c_float * 3
+_L3 = c_int64 * 3
 
 _SIGNATURES = {
     "m3d_version": (c_int, []),
@@ -159,6 +175,20 @@ _SIGNATURES = {
     "m3d_moments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "m3d_normalized_sq_diff": (
         c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    # include/m3d_io.h
+    "m3d_blosc_info": (c_int, [c_void_p, c_size_t, POINTER(BloscHeader)]),
+    "m3d_blosc_decode_host": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t]),
+    "m3d_blosc_bound": (c_size_t, [c_size_t, c_size_t]),
+    "m3d_blosc_encode_host": (
+        c_int, [c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_size_t, c_void_p, c_size_t, POINTER(c_size_t)]),
+    "m3d_io_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "m3d_io_destroy": (None, [c_void_p]),
+    "m3d_zarr_read_device": (c_int, [c_void_p, c_char_p, _L3, _L3, c_int, c_void_p, c_void_p, POINTER(IOStats)]),
+    "m3d_zarr_read_host": (c_int, [c_void_p, c_char_p, _L3, _L3, c_int, c_void_p, POINTER(IOStats)]),
+    "m3d_zarr_write_device": (
+        c_int, [c_void_p, c_char_p, _L3, _L3, c_int, c_void_p, c_int, c_int, c_int, c_void_p, POINTER(IOStats)]),
+    "m3d_zarr_write_host": (
+        c_int, [c_void_p, c_char_p, _L3, _L3, c_int, c_void_p, c_int, c_int, c_int, POINTER(IOStats)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -207,6 +237,10 @@ def check(status: int, what: str = "") -> None:
 
 def i3(values) -> ctypes.Array:
     return _I3(*[int(v) for v in values])
+
+
+def l3(values) -> ctypes.Array:
+    return _L3(*[int(v) for v in values])
 
 
 def f3(values) -> ctypes.Array:

@@ -244,3 +244,97 @@ class InMemoryDataStore:
 
     def load_global_cellpose_roi_zip(self):
         return None
+
+
+class _DiskImages:
+    """Dictionary face of one image family kept as ``<entity>/<name>.ome.zarr`` stores on disk."""
+
+    def __init__(self, owner: "ZarrImageDataStore", name: str):
+        self._owner, self._name = owner, name
+
+    def path(self, key) -> Path:
+        tile, kind, ident = key
+        root = self._owner._fiducial_root_path if kind == "round" else self._owner._readouts_root_path
+        return root / tile / ident / self._name
+
+    def __contains__(self, key) -> bool:
+        from . import zarr_io
+
+        return key is not None and (zarr_io.image_store_path(self.path(key)) / "0" / "zarr.json").exists()
+
+    def __setitem__(self, key, image) -> None:
+        spacing = self._owner.voxel_size_zyx_um
+        self._owner._io.write_image(self.path(key), image, ome_scale=spacing)
+
+    def __getitem__(self, key):
+        return self._owner._io.read_image(self.path(key), device=self._owner._device)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def shape(self, key):
+        return self._owner._io.image_shape(self.path(key)) if key in self else None
+
+
+class ZarrImageDataStore(InMemoryDataStore):
+    """The same duck type with every image on disk in the reference's layout and format
+    (``<root>/fiducial/<tile>/<round>/{corrected_data,decon_data,opticalflow_xform_px}.ome.zarr``,
+    ``<root>/readouts/<tile>/<bit>/{corrected_data,decon_data,<predictor>_data}.ome.zarr``;
+    qi2labDataStore.py:1310-1332, 3592-3619, 4087, 4491, 4690), read and written through the
+    I/O fast path (``zarr_io.ImageIO``).  ``device="cuda:0"`` makes every ``load_*`` return a tensor
+    already in HBM (zstd on host threads, bit shuffle + chunk scatter on the GPU).  Scalars, transforms and
+    tables stay in memory: the reference's JSON / parquet sidecars are outside the hot path.
+    """
+
+    def __init__(self, datastore_path, *, device=None, num_threads=None, **kwargs):
+        from . import zarr_io
+
+        super().__init__(datastore_path=datastore_path, **kwargs)
+        self._device = device
+        self._io = zarr_io.ImageIO(num_threads=num_threads)
+        self.fiducial_folder_name = "fiducial"
+        self._fiducial_root_path = self._datastore_path / self.fiducial_folder_name
+        self._readouts_root_path = self._datastore_path / "readouts"
+        for p in (self._fiducial_root_path, self._readouts_root_path):
+            p.mkdir(parents=True, exist_ok=True)
+        self._corrected = _DiskImages(self, "corrected_data")
+        self._fiducial_decon = _DiskImages(self, "decon_data")
+        self._readout_decon = _DiskImages(self, "decon_data")
+        self._predictor = _DiskImages(self, f"{self.feature_predictor_folder_name}_data")
+
+    def _image_shape(self, tile, round=None, bit=None, kind="corrected_data"):
+        """By keys like the in-memory store, or - the reference's form (qi2labDataStore.py:1835-1862) -
+        by the logical image path ``<entity root>/<image name>``."""
+        if round is None and bit is None:
+            from . import zarr_io
+
+            path = zarr_io.image_store_path(tile)
+            return self._io.image_shape(path) if (path / "0" / "zarr.json").exists() else None
+        k = self._key(tile, round, bit)
+        if k is None:
+            return None
+        if kind == "corrected_data":
+            return self._corrected.shape(k)
+        if kind in ("decon_data", "registered_decon_data"):
+            return (self._readout_decon if k[1] == "bit" else self._fiducial_decon).shape(k)
+        if kind == f"{self.feature_predictor_folder_name}_data":
+            return self._predictor.shape(k)
+        return None
+
+    def _flow_path(self, tile, round) -> Path:
+        return self._fiducial_root_path / self._tile(tile) / self._round(round) / "opticalflow_xform_px"
+
+    def save_local_sofima_flow_field(self, sofima_flow_field_xyz_px, *, tile, round, **attrs):
+        """Flow ``<f4 (3, z, y, x)`` with its map attributes as image-level attributes
+        (DataRegistration.py:661-674, qi2labDataStore.py:4171-4190)."""
+        attrs.pop("return_future", None)
+        self._io.write_image(self._flow_path(tile, round), np.asarray(sofima_flow_field_xyz_px, dtype=np.float32),
+                             extra_attributes=attrs)
+
+    def load_local_sofima_flow_field(self, tile, round, return_future=False):
+        from . import zarr_io
+
+        path = self._flow_path(tile, round)
+        if not (zarr_io.image_store_path(path) / "0" / "zarr.json").exists():
+            return None
+        return self._io.read_image(path), zarr_io.read_extra_attributes(path)

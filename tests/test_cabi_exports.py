@@ -1,4 +1,4 @@
-"""CPU: libm3d_hip.so loads and exports every function include/m3d_hip.h declares."""
+"""CPU: libm3d_hip.so loads and exports every function include/*.h declares."""
 
 import re
 
@@ -6,9 +6,11 @@ from conftest import ROOT, pkg
 
 
 def _declared_functions():
-    text = (ROOT / "include" / "m3d_hip.h").read_text()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(m3d_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in sorted((ROOT / "include").glob("*.h")):
+        text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
+        names |= set(re.findall(r"\b(m3d_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

@@ -49,13 +49,18 @@ def _render(points, amps, sigma):
     return gaussian_filter(vol, sigma)
 
 
-def _experiment(seed=0):
-    """(store, truth table, per-round shifts): 2 tiles side by side in y with a 28-px overlap."""
+def _experiment(seed=0, zarr_root=None):
+    """(store, truth table, per-round shifts): 2 tiles side by side in y with a 28-px overlap.
+    ``zarr_root``: keep every image on disk as OME-Zarr and load it straight into HBM (I/O fast path)."""
     ds_mod = pkg("datastore")
     rng = np.random.default_rng(seed)
     bits, genes = _codebook()
-    store = ds_mod.InMemoryDataStore(num_tiles=2, num_rounds=N_ROUNDS, num_bits=N_BITS,
-                                     codebook=codebook_frame(bits, genes), voxel_size_zyx_um=VOXEL)
+    kwargs = dict(num_tiles=2, num_rounds=N_ROUNDS, num_bits=N_BITS, codebook=codebook_frame(bits, genes),
+                  voxel_size_zyx_um=VOXEL)
+    if zarr_root is None:
+        store = ds_mod.InMemoryDataStore(**kwargs)
+    else:
+        store = ds_mod.ZarrImageDataStore(zarr_root, device="cuda:0", num_threads=4, **kwargs)
     store.channel_psfs = [_psf((0.9, 1.2, 1.2)), _psf((0.9, 1.3, 1.3)), _psf((0.9, 1.4, 1.4))]
     shifts = {r: (0.0, 0.0, 0.0) if r == 0 else tuple(np.round(rng.uniform((-1, -4, -4), (1, 4, 4)), 0))
               for r in range(N_ROUNDS)}
@@ -91,10 +96,10 @@ def _experiment(seed=0):
     return store, truth, shifts, predictors
 
 
-@pytest.mark.parametrize("deformable", [False, True])
-def test_preprocess_then_decode_recovers_the_planted_transcripts(deformable):
+@pytest.mark.parametrize("deformable,on_disk", [(False, False), (True, False), (True, True)])
+def test_preprocess_then_decode_recovers_the_planted_transcripts(deformable, on_disk, tmp_path):
     DR, PD, sc = pkg("DataRegistration"), pkg("PixelDecoder"), pkg("scoring")
-    store, truth, shifts, predictors = _experiment()
+    store, truth, shifts, predictors = _experiment(zarr_root=tmp_path / "qi2lab" if on_disk else None)
     state = {}
 
     def predictor(image):

@@ -1,0 +1,119 @@
+"""GPU parity: chunk files <-> volumes in HBM (m3d_zarr_read_device / m3d_zarr_write_device) against the
+NumPy restatement (oracle/blosc_ref.py) and the real c-blosc frames of tests/golden/blosc_frames.npz."""
+
+import ctypes
+import filecmp
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import blosc_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _volume(rng, shape, dtype):
+    z, y, x = np.indices(shape)
+    base = 300 + 100 * np.sin(0.2 * x) * np.cos(0.13 * y) + 10 * z
+    v = rng.poisson(base).astype(np.float64)
+    return (v / 977.0).astype(dtype) if np.dtype(dtype).kind == "f" else v.astype(dtype)
+
+
+@pytest.fixture()
+def io_handle():
+    hip = pkg("_hip")
+    lib = hip.lib()
+    handle = ctypes.c_void_p()
+    hip.check(lib.m3d_io_create(4, ctypes.byref(handle)))
+    yield hip, lib, handle
+    lib.m3d_io_destroy(handle)
+
+
+@pytest.mark.parametrize("shape,chunks,dtype,shuffle", [
+    ((5, 70, 90), (2, 32, 32), np.uint16, 2), ((20, 130, 260), (16, 64, 128), np.uint16, 2),
+    ((3, 64, 64), (3, 64, 64), np.float32, 2), ((1, 33, 47), (16, 512, 512), np.uint16, 2),
+    ((9, 40, 24), (4, 16, 8), np.uint8, 2), ((6, 50, 70), (4, 32, 32), np.uint16, 1),
+    ((6, 50, 70), (4, 32, 32), np.float32, 0), ((4, 31, 37), (2, 9, 11), np.uint16, 2)])
+def test_read_device_matches_the_restatement(tmp_path, io_handle, shape, chunks, dtype, shuffle):
+    hip, lib, handle = io_handle
+    vol = _volume(np.random.default_rng(4), shape, dtype)
+    T = vol.dtype.itemsize
+    d = tmp_path / "c"
+    blosc_ref.write_array(d, vol, chunks, shuffle=shuffle)
+    out = torch.full(shape, 7, dtype=getattr(torch, vol.dtype.name), device=DEV)
+    stats = hip.IOStats()
+    hip.check(lib.m3d_zarr_read_device(handle, str(d).encode(), hip.l3(shape), hip.l3(chunks), T, out.data_ptr(),
+                                       hip.current_stream(out.device), ctypes.byref(stats)))
+    assert np.array_equal(out.cpu().numpy(), vol)
+    grid = [-(-s // c) for s, c in zip(shape, chunks)]
+    last = [g - 1 for g in grid]
+    d.joinpath(*[str(i) for i in last]).unlink()
+    out.fill_(9)
+    hip.check(lib.m3d_zarr_read_device(handle, str(d).encode(), hip.l3(shape), hip.l3(chunks), T, out.data_ptr(),
+                                       hip.current_stream(out.device), ctypes.byref(stats)))
+    want = vol.copy()
+    want[tuple(slice(i * c, None) for i, c in zip(last, chunks))] = 0
+    assert np.array_equal(out.cpu().numpy(), want) and stats.chunks_missing == 1
+
+
+@pytest.mark.parametrize("shape,chunks,dtype", [((5, 70, 90), (2, 32, 32), np.uint16), ((20, 130, 260), (16, 64, 128), np.uint16),
+                                                ((3, 64, 64), (3, 64, 64), np.float32), ((4, 31, 37), (2, 9, 11), np.uint16),
+                                                ((9, 40, 24), (4, 16, 8), np.uint8)])
+def test_write_device_files_equal_the_host_writer_and_decode_in_the_restatement(tmp_path, io_handle, shape, chunks, dtype):
+    hip, lib, handle = io_handle
+    vol = _volume(np.random.default_rng(5), shape, dtype)
+    T = vol.dtype.itemsize
+    dev = torch.from_numpy(vol).to(DEV)
+    stats = hip.IOStats()
+    d_dev, d_host = tmp_path / "dev" / "c", tmp_path / "host" / "c"
+    hip.check(lib.m3d_zarr_write_device(handle, str(d_dev).encode(), hip.l3(shape), hip.l3(chunks), T, dev.data_ptr(), 5, 2, 4,
+                                        hip.current_stream(dev.device), ctypes.byref(stats)))
+    hip.check(lib.m3d_zarr_write_host(handle, str(d_host).encode(), hip.l3(shape), hip.l3(chunks), T, vol.ctypes.data, 5, 2, 4,
+                                      ctypes.byref(stats)))
+    assert np.array_equal(blosc_ref.read_array(d_dev, shape, chunks, vol.dtype), vol)
+    grid = [-(-s // c) for s, c in zip(shape, chunks)]
+    for z in range(grid[0]):
+        for y in range(grid[1]):
+            for x in range(grid[2]):
+                rel = f"{z}/{y}/{x}"
+                assert filecmp.cmp(d_dev / rel, d_host / rel, shallow=False), rel
+
+
+def test_cblosc_frames_as_chunks(tmp_path, io_handle, golden):
+    """Frames written by the real c-blosc 1.21: several blocks, a short last block that c-blosc leaves
+    unshuffled, lz4 split streams, a memcpyed frame."""
+    hip, lib, handle = io_handle
+    g = golden("blosc_frames")
+    for i, name in enumerate(g["names"]):
+        raw = g[f"raw_{i}"]
+        shape = (1, 1, raw.size)
+        d = tmp_path / str(name) / "c" / "0" / "0"
+        d.mkdir(parents=True)
+        g[f"frame_{i}"].tofile(d / "0")
+        out = torch.zeros(shape, dtype=getattr(torch, raw.dtype.name), device=DEV)
+        hip.check(lib.m3d_zarr_read_device(handle, str(d.parents[1]).encode(), hip.l3(shape), hip.l3(shape),
+                                           raw.dtype.itemsize, out.data_ptr(), hip.current_stream(out.device), None), str(name))
+        assert np.array_equal(out.cpu().numpy().ravel(), raw), name
+
+
+def test_image_store_round_trip_in_hbm(tmp_path):
+    zio = pkg("zarr_io")
+    rng = np.random.default_rng(6)
+    with zio.ImageIO(num_threads=8) as io:
+        vol = torch.from_numpy(_volume(rng, (40, 700, 900), np.uint16)).to(DEV)
+        root = io.write_image(tmp_path / "readouts" / "tile0000" / "bit001" / "decon_data", vol,
+                              ome_scale=(0.315, 0.098, 0.098), extra_attributes={"deconvolution": True})
+        w = dict(io.last_stats)
+        back = io.read_image(root, device=DEV)
+        assert back.dtype == torch.uint16 and torch.equal(back, vol)
+        assert np.array_equal(io.read_image(root), vol.cpu().numpy())           # all-host path, same files
+        assert w["chunks"] == 3 * 2 * 2 and w["file_bytes"] < w["raw_bytes"]
+        flow = torch.from_numpy(rng.normal(size=(3, 5, 30, 40)).astype(np.float32)).to(DEV)
+        io.write_image(tmp_path / "flow", flow)
+        assert torch.equal(io.read_image(tmp_path / "flow", device=DEV), flow)
+        pred = torch.from_numpy(rng.uniform(size=(20, 300, 520)).astype(np.float32)).to(DEV)
+        io.write_image(tmp_path / "feature_predictor_data", pred)
+        assert torch.equal(io.read_image(tmp_path / "feature_predictor_data", device=DEV), pred)
