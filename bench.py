@@ -378,7 +378,9 @@ def main() -> None:
             rows, vox = fz * fy, fz * fy * fx
             x_small = 4.0 * vox + 4.0 * rows   # real rows of the core <-> their half spectra
             y_small = 4.0 * rows + 4.0 * fz    # core z planes: core y rows <-> all ky
-            moved = ((x_small + 8.0) / 2, (y_small + 8.0) / 2, 4.0 + 4.0 + 4.0 * fz, (y_small + 8.0) / 2,
+            # (the estimate's convolution builds only the core planes in its Y pass and mirrors them in the
+            # Z pass's LDS, so three of the four forward Y passes are "small" and Z moves 5 fz + 7 on average)
+            moved = ((x_small + 8.0) / 2, (3.0 * y_small + 8.0) / 4, 5.0 * fz + 7.0, (y_small + 8.0) / 2,
                      (x_small + 8.0) / 2)
             out["roofline_kernels"] = [
                 {"kernel": nme, "avg_ms": round(ms / stats["conv_calls"], 3),

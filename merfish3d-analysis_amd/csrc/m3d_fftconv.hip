@@ -50,7 +50,7 @@ struct FftConvPlan {
     void *tables = nullptr;  // one device allocation holding all twiddle / pos tables
     size_t lds_x, lds_y, lds_z;
     int rset_x, rset_y, rset_z;  // 1: lean kernels (no radix 16 / 8 stage on that axis)
-    int ythreads, zthreads, xthreads, gx, gy, gz, dual_rows, dual_threads;
+    int ythreads, zthreads, xthreads, gx, gy, gz, dual_rows, dual_threads, zmirror;
 };
 
 }  // namespace m3d
@@ -66,6 +66,7 @@ struct ConvGeo {
     m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
     m3d::ConvBox mir;      // mirror != 0: the input is the symmetric extension of this box
     int mirror;
+    int zmirror;           // the spectrum holds the box's z planes only; the Z pass mirrors them in LDS
 };
 
 __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, int k)
@@ -464,7 +465,8 @@ __global__ __launch_bounds__(1024) void k_y_forward_mirror(const float2 *__restr
 {
     extern __shared__ float2 lds_ym[];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int z = blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
+    // zmirror: only the core planes are built (the Z pass reflects them); else every plane from its source
+    const int z = (g.zmirror ? g.mir.z0 : 0) + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
     const int zs = sym_src(z, g.mir.z0, g.mir.nz);
     const float2 *stile = src + ((int64_t)zs * g.nT + kt) * g.Yp * g.TW;
     float2 *dtile = dst + ((int64_t)z * g.nT + kt) * g.Yp * g.TW;
@@ -514,8 +516,9 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
     const int64_t pc = live ? p0 + p : g.plane - 1;
     float2 *col = spec + pc;
     const int zin_hi = g.in.z0 + g.in.nz;
-    for (int z = z0; z < g.Zp; z += zstep)  // planes outside the input's support are zero
-        if (z < g.in.z0 || z >= zin_hi) lds_z[(z << g.lP) + p] = make_float2(0.f, 0.f);
+    if (!g.zmirror)
+        for (int z = z0; z < g.Zp; z += zstep)  // planes outside the input's support are zero
+            if (z < g.in.z0 || z >= zin_hi) lds_z[(z << g.lP) + p] = make_float2(0.f, 0.f);
     {
         const int first = g.in.z0 + ((z0 - g.in.z0) % zstep + zstep) % zstep;  // first z >= in.z0, = z0 mod zstep
         for (int zb = first; zb < zin_hi; zb += zstep * kU) {
@@ -531,6 +534,11 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
                 if (z < zin_hi) lds_z[(z << g.lP) + p] = live ? v[u] : make_float2(0.f, 0.f);
             }
         }
+    }
+    if (g.zmirror) {  // symmetric extension along z: the other planes are copies of the loaded ones
+        __syncthreads();
+        for (int z = z0; z < g.Zp; z += zstep)
+            if (z < g.in.z0 || z >= zin_hi) lds_z[(z << g.lP) + p] = lds_z[(sym_src(z, g.in.z0, g.in.nz) << g.lP) + p];
     }
     __syncthreads();
     lds_fft<false, RSET>(lds_z, az, P, P, 1, tid, nt, g.GZ);
@@ -623,6 +631,7 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
     g.out = out ? *out : full;
     g.mir = mirror ? *mirror : full;
     g.mirror = mirror ? 1 : 0;  // callers set 2 for the rows-of-the-box-only variant
+    g.zmirror = 0;
     g.Zp = p->Zp;
     g.Yp = p->Yp;
     g.Xp = p->Xp;
@@ -692,6 +701,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->gx = knob("M3D_FFT_GX", 4);
     p->gy = knob("M3D_FFT_GY", 4);
     p->gz = knob("M3D_FFT_GZ", 4);
+    p->zmirror = knob("M3D_FFT_ZMIRROR", 1) ? 1 : 0;
     p->dual_rows = knob("M3D_FFT_DUAL_ROWS", 2);
     p->dual_threads = knob("M3D_FFT_DUAL_T", 256);
     p->ythreads = knob("M3D_FFT_YT", 768);
@@ -796,6 +806,8 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         // every plane from the core plane it mirrors (out of place: spec -> spec_alt)
         ConvGeo g = geo_of(p, mirror_box, nullptr, mirror_box);
         g.mirror = 2;
+        g.zmirror = p->zmirror;
+        const unsigned yplanes = (unsigned)(p->zmirror ? g.mir.nz : p->Zp);
         const int groups = row_groups(p, g.in);
         if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
         if (p->rset_x)
@@ -804,9 +816,9 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
             hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
         if (p->rset_y)
-            hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
+            hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
         else
-            hipLaunchKernelGGL(k_y_forward_mirror<0>, dim3((unsigned)(p->Zp * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
+            hipLaunchKernelGGL(k_y_forward_mirror<0>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
         M3D_KERNEL_CHECK();
         return M3D_OK;
     }
@@ -860,10 +872,12 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
         return M3D_ERR_INVALID_ARG;
     int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box, spec_alt);
     if (rc) return rc;
-    if (src && mirror_box && spec_alt && p->TW % 2 == 0) spec = spec_alt;  // the mirrored Y pass wrote there
+    const bool mirrored = src && mirror_box && spec_alt && p->TW % 2 == 0;
+    if (mirrored) spec = spec_alt;  // the mirrored Y pass wrote there
     if (rows) *rows = spec;
     if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
-    const ConvGeo g = geo_of(p, in_box, out_box);
+    ConvGeo g = geo_of(p, (mirrored && p->zmirror) ? mirror_box : in_box, out_box);
+    g.zmirror = (mirrored && p->zmirror) ? 1 : 0;
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
     if (p->rset_z == 2)
