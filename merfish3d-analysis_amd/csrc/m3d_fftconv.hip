@@ -29,6 +29,9 @@ using namespace m3d;
 
 // loads kept in flight per thread in the load phase of each pass (measured on MI355X)
 #ifndef M3D_KU_Z
+#ifndef M3D_KH_Z
+#define M3D_KH_Z 16
+#endif
 #define M3D_KU_Z 8
 #endif
 #ifndef M3D_KU_Y
@@ -516,6 +519,16 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
     const int64_t pc = live ? p0 + p : g.plane - 1;
     float2 *col = spec + pc;
     const int zin_hi = g.in.z0 + g.in.nz;
+    // The OTF column is requested before anything else so that its latency hides behind the spectrum
+    // loads and the forward transform (kH values per thread; longer columns fall back to loading it late).
+    constexpr int kH = M3D_KH_Z;
+    const float2 *hcol = otf + pc;
+    const bool early = kH > 0 && mode >= 0 && g.Zp <= kH * zstep;
+    float2 hreg[kH > 0 ? kH : 1];
+    if (early) {
+#pragma unroll
+        for (int i = 0; i < kH; ++i) hreg[i] = hcol[(int64_t)min(z0 + i * zstep, g.Zp - 1) * g.plane];
+    }
     if (!g.zmirror)
         for (int z = z0; z < g.Zp; z += zstep)  // planes outside the input's support are zero
             if (z < g.in.z0 || z >= zin_hi) lds_z[(z << g.lP) + p] = make_float2(0.f, 0.f);
@@ -547,7 +560,18 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
             if (live) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
         return;
     }
-    const float2 *hcol = otf + pc;
+    if (early) {
+#pragma unroll
+        for (int i = 0; i < kH; ++i) {
+            const int z = z0 + i * zstep;
+            if (z >= g.Zp) continue;
+            float2 h = hreg[i];
+            if (mode == 1) h.y = -h.y;
+            if (mode == 2) h = make_float2(h.x * h.x + h.y * h.y, 0.0f);
+            const float2 v = cmul(lds_z[(z << g.lP) + p], h);
+            lds_z[(z << g.lP) + p] = make_float2(v.x * scale, v.y * scale);
+        }
+    } else
     for (int zb = z0; zb < g.Zp; zb += zstep * kU) {
         float2 hv[kU];
 #pragma unroll
