@@ -190,6 +190,52 @@ def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tu
     return float(t.item()), float(it.item())
 
 
+def io_leg(readouts, predictors, n_bits, step_seconds, voxels, sample_bits=4):
+    """Datastore image I/O beside the compute: a sample of the tile's readout (uint16) and
+    predictor (float32) images is written as OME-Zarr / Blosc-zstd stores and loaded back into HBM through
+    ``zarr_io.ImageIO`` (zstd on host threads, bit shuffle + scatter on the GPU); per-tile figures are the
+    sample scaled to all bits.  Reported next to ``value``, never part of it."""
+    import shutil
+    import tempfile
+
+    zio = importlib.import_module("merfish3d-analysis_amd.zarr_io")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    root = Path(tempfile.mkdtemp(prefix="m3d_bench_io_", dir=base))
+    k = min(sample_bits, n_bits)
+    try:
+        with zio.ImageIO() as io:
+            t0 = time.perf_counter()
+            raw = files = 0
+            for b in range(k):
+                for name, img in (("corrected_data", readouts[b]), ("feature_predictor_data", predictors[b])):
+                    io.write_image(root / f"bit{b + 1:03d}" / name, img)
+                    raw += io.last_stats["raw_bytes"]
+                    files += io.last_stats["file_bytes"]
+            t_write = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ok = True
+            for b in range(k):
+                a = io.read_image(root / f"bit{b + 1:03d}" / "corrected_data", device=readouts[b].device)
+                p = io.read_image(root / f"bit{b + 1:03d}" / "feature_predictor_data", device=readouts[b].device)
+                ok = ok and a.shape == readouts[b].shape and p.dtype == predictors[b].dtype
+            torch.cuda.synchronize()
+            t_read = time.perf_counter() - t0
+            ok = ok and torch.equal(a, readouts[k - 1]) and torch.equal(p, predictors[k - 1])
+            threads = io.num_threads
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    load_tile = t_read * n_bits / k
+    return {
+        "what": f"{k} of {n_bits} bits: readout uint16 + predictor float32 images, OME-Zarr 0.5 / Zarr v3 / "
+                f"Blosc zstd-5 bitshuffle chunks (16x512x512) on {'tmpfs' if base else 'local disk'}, device path",
+        "host_threads": threads, "round_trip_equal": bool(ok),
+        "read_GBps": round(raw / t_read / 1e9, 2), "write_GBps": round(raw / t_write / 1e9, 2),
+        "compression_ratio": round(raw / max(files, 1), 2),
+        "load_seconds_per_tile": round(load_tile, 3),
+        "value_including_load": round(voxels / (step_seconds + load_tile) / 1e6, 4), "unit": "Mvoxels/s",
+    }
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -424,6 +470,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             iters_per_bit = total_iters / max(args.steps * n_bits, 1)
             out["cpu_baseline"] = cpu_baseline(readouts[0], psf, bits_matrix, shape, n_bits, iters_per_bit)
+            out["io"] = io_leg(readouts, predictors, n_bits, out["ms_per_step"] / 1e3, float(np.prod(shape)))
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
