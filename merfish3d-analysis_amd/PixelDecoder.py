@@ -1019,7 +1019,11 @@ class PixelDecoder:
         if distributed or self._num_gpus == 1:
             gpu = _torch().cuda.current_device() if distributed else 0
             self._optimize_normalization_weights = False
-            for tile_idx in shards[0]:
+            mine = list(shards[0])
+            prefetch = getattr(self._datastore, "prefetch_tile", None)  # disk-backed store: load the next
+            for n, tile_idx in enumerate(mine):                          # tile's images under this tile's compute
+                if prefetch is not None and n + 1 < len(mine):
+                    prefetch(mine[n + 1], bits=self._datastore.bit_ids[: self._n_merfish_bits])
                 self.decode_one_tile(tile_idx=tile_idx, gpu_id=gpu, lowpass_sigma=lowpass_sigma,
                                      magnitude_threshold=magnitude_threshold,
                                      minimum_pixels=minimum_pixels,

@@ -264,9 +264,13 @@ class _DiskImages:
 
     def __setitem__(self, key, image) -> None:
         spacing = self._owner.voxel_size_zyx_um
+        self._owner._drop_prefetched(self.path(key))
         self._owner._io.write_image(self.path(key), image, ome_scale=spacing)
 
     def __getitem__(self, key):
+        ready = self._owner._take_prefetched(self.path(key))
+        if ready is not None:
+            return ready
         return self._owner._io.read_image(self.path(key), device=self._owner._device)
 
     def get(self, key, default=None):
@@ -292,6 +296,10 @@ class ZarrImageDataStore(InMemoryDataStore):
         super().__init__(datastore_path=datastore_path, **kwargs)
         self._device = device
         self._io = zarr_io.ImageIO(num_threads=num_threads)
+        self._prefetched = {}        # image path -> Future[tensor in HBM]
+        self._prefetch_pool = None
+        self._prefetch_io = None
+        self._prefetch_stream = None
         self.fiducial_folder_name = "fiducial"
         self._fiducial_root_path = self._datastore_path / self.fiducial_folder_name
         self._readouts_root_path = self._datastore_path / "readouts"
@@ -320,6 +328,58 @@ class ZarrImageDataStore(InMemoryDataStore):
         if kind == f"{self.feature_predictor_folder_name}_data":
             return self._predictor.shape(k)
         return None
+
+    # ---- read-ahead: the next tile's images are loaded on a side stream while this tile computes ----
+    def prefetch_tile(self, tile, bits=None) -> int:
+        """Start loading the images ``decode_one_tile`` will ask for (per bit: the deconvolved readout if it
+        exists, else the corrected one, and the predictor image) into HBM; returns how many loads were queued.
+        The loads run in one background thread with its own reader (zstd on its host threads) and its own
+        HIP stream, so PCIe copies and the unshuffle kernels overlap the current tile's kernels."""
+        if self._device is None:
+            return 0
+        from concurrent.futures import ThreadPoolExecutor
+
+        if self._prefetch_pool is None:
+            self._prefetch_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="m3d-prefetch")
+        t = self._tile(tile)
+        queued = 0
+        for bit in (self.bit_ids if bits is None else bits):
+            k = self._key(t, bit=bit)
+            if k is None:
+                continue
+            src = self._readout_decon if k in self._readout_decon else self._corrected
+            for family in (src, self._predictor):
+                path = family.path(k)
+                if k in family and path not in self._prefetched:
+                    self._prefetched[path] = self._prefetch_pool.submit(self._prefetch_one, path)
+                    queued += 1
+        return queued
+
+    def _prefetch_one(self, path):
+        import torch
+
+        from . import zarr_io
+
+        if self._prefetch_io is None:
+            self._prefetch_io = zarr_io.ImageIO(num_threads=self._io.num_threads)
+            self._prefetch_stream = torch.cuda.Stream(device=self._device)
+        with torch.cuda.stream(self._prefetch_stream):
+            return self._prefetch_io.read_image(path, device=self._device)   # returns after its stream drained
+
+    def _take_prefetched(self, path):
+        fut = self._prefetched.pop(path, None)
+        if fut is None:
+            return None
+        import torch
+
+        tensor = fut.result()
+        tensor.record_stream(torch.cuda.current_stream(tensor.device))  # allocated under the side stream
+        return tensor
+
+    def _drop_prefetched(self, path) -> None:
+        fut = self._prefetched.pop(path, None)
+        if fut is not None:
+            fut.result()
 
     def _flow_path(self, tile, round) -> Path:
         return self._fiducial_root_path / self._tile(tile) / self._round(round) / "opticalflow_xform_px"

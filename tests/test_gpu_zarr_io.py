@@ -117,3 +117,39 @@ def test_image_store_round_trip_in_hbm(tmp_path):
         pred = torch.from_numpy(rng.uniform(size=(20, 300, 520)).astype(np.float32)).to(DEV)
         io.write_image(tmp_path / "feature_predictor_data", pred)
         assert torch.equal(io.read_image(tmp_path / "feature_predictor_data", device=DEV), pred)
+
+
+def test_tile_read_ahead_hands_over_the_same_images(tmp_path):
+    """prefetch_tile loads on a side stream in a background thread; load_* must return the same tensors as a
+    direct read, consume the read-ahead entry, and a later write must not be shadowed by a stale entry."""
+    ds = pkg("datastore")
+    from helpers import codebook_frame
+
+    rng = np.random.default_rng(8)
+    store = ds.ZarrImageDataStore(tmp_path / "qi2lab", device=DEV, num_threads=4, num_tiles=2, num_rounds=1,
+                                  num_bits=3, codebook=codebook_frame(np.ones((3, 3), dtype=np.int64)))
+    imgs = {}
+    for t in range(2):
+        for b in range(3):
+            img = rng.integers(90, 5000, size=(20, 140, 300)).astype(np.uint16)
+            pred = rng.uniform(size=img.shape).astype(np.float32)
+            store.set_corrected_image(img, tile=t, bit=b)
+            store.save_local_feature_predictor_image(pred, tile=t, bit=b)
+            imgs[(t, b)] = (img, pred)
+    store.save_local_deconvolved_readout_image(imgs[(1, 2)][0] // 2, tile=1, bit=2)   # decon shadows corrected
+    assert store.prefetch_tile(1) == 6 and len(store._prefetched) == 6
+    assert store.prefetch_tile(1) == 0                                               # already queued
+    busy = torch.ones((2048, 2048), device=DEV)
+    for _ in range(20):
+        busy = busy @ busy * 1e-4                                                      # compute on the main stream meanwhile
+    for b in range(3):
+        want = imgs[(1, b)][0] // 2 if b == 2 else imgs[(1, b)][0]
+        got = store.load_local_readout_image(1, bit=b, return_future=False)
+        assert got.is_cuda and np.array_equal(got.cpu().numpy(), want)
+        assert np.array_equal(store.load_local_feature_predictor_image(1, bit=b, return_future=False).cpu().numpy(),
+                              imgs[(1, b)][1])
+    assert not store._prefetched
+    store.prefetch_tile(0, bits=store.bit_ids[:1])
+    store.set_corrected_image(imgs[(0, 0)][0] + 7, tile=0, bit=0)                     # invalidates the read-ahead
+    assert np.array_equal(store.load_local_readout_image(0, bit=0, return_future=False).cpu().numpy(), imgs[(0, 0)][0] + 7)
+    torch.cuda.synchronize()
