@@ -114,6 +114,37 @@ int m3d_rlgc_run(m3d_rlgc_plan *plan, const void *image, int image_dtype, const 
                  const m3d_rlgc_params *params, const float *injected_splits, int n_injected,
                  m3d_rlgc_result *result_host, void *stream);
 
+/* ---- the solver's building blocks, stand-alone (module-level functions of utils/rlgc.py;
+ *      m3d_rlgc_run runs fused versions of the same arithmetic) ---------------------------- */
+/* filter_update ElementwiseKernel, rlgc.py:23-31: out = consensus < 0 ? recon : recon * HTratio */
+int m3d_filter_update(const float *recon, const float *htratio, const float *consensus_map, float *out, int64_t n,
+                      void *stream);
+/* enforce_symmetric_boundary, rlgc.py:230-271 (+ _symmetric_padded_axis_indices :203-227), in place */
+int m3d_enforce_symmetric_boundary(float *volume, const int32_t padded_zyx[3], const int32_t pad_before[3],
+                                   const int32_t pad_after[3], void *stream);
+/* _observed_region_mask, rlgc.py:353-379 */
+int m3d_observed_region_mask(float *mask, const int32_t padded_zyx[3], const int32_t pad_before[3],
+                             const int32_t pad_after[3], void *stream);
+/* pad_psf, rlgc.py:274-313: zero-embed, centre (the 6 rolls + ifftshift), optional unit sum */
+size_t m3d_pad_psf_workspace_bytes(void);
+int m3d_pad_psf(const float *psf, const int32_t psf_zyx[3], float *out, const int32_t padded_zyx[3], int normalize,
+                void *work, size_t work_bytes, void *stream);
+/* kl_div, rlgc.py:382-412 (mask may be NULL); synchronises the stream and writes one host double */
+size_t m3d_kl_div_workspace_bytes(void);
+int m3d_kl_div(const float *p, const float *q, const float *mask, int64_t n, void *work, size_t work_bytes,
+               double *result_host, void *stream);
+/* fft_conv, rlgc.py:316-350, on the fused FFT engine (axes 2^a 3^b; else M3D_ERR_UNSUPPORTED):
+ * the transfer function lives in the engine's tiled spectrum layout, so it is made by m3d_fftconv_otf from the
+ * padded PSF (rlgc.py:582 `rfftn(psf)`) and applied as H (mode 0), conj H (1) or |H|^2 (2) (rlgc.py:583-585).
+ * `otf` and `scratch_spectrum` are device buffers of m3d_fftconv_spectrum_bytes(); image may equal out. */
+typedef struct m3d_fftconv m3d_fftconv;
+int m3d_fftconv_create(const int32_t shape_zyx[3], m3d_fftconv **out);
+int m3d_fftconv_destroy(m3d_fftconv *handle);
+size_t m3d_fftconv_spectrum_bytes(const m3d_fftconv *handle);
+int m3d_fftconv_otf(m3d_fftconv *handle, const float *psf_padded, void *otf, void *stream);
+int m3d_fftconv_apply(m3d_fftconv *handle, const float *image, const void *otf, int mode, void *scratch_spectrum,
+                      float *out, void *stream);
+
 /* Philox split of one iteration, for the parity tests of the sampler itself. */
 int m3d_rlgc_debug_split(const void *image, int image_dtype, int64_t n, uint64_t seed,
                          int32_t iteration, float *split1, void *stream);

@@ -50,6 +50,16 @@ def _registration_diag(message: str, *, enabled: bool = False) -> None:
         print(f"{_REGISTRATION_DIAG_PREFIX} {message}", flush=True)
 
 
+def _restrict_worker_to_assigned_gpu(gpu_id: int) -> int:
+    """Restrict a spawned worker process to one physical GPU before anything initialises HIP
+    (DataRegistration.py:151-167: ``CUDA_VISIBLE_DEVICES`` there, ``HIP_VISIBLE_DEVICES`` on ROCm);
+    the device is index 0 inside the worker afterwards."""
+    import os
+
+    os.environ["HIP_VISIBLE_DEVICES"] = str(int(gpu_id))
+    return 0
+
+
 def time_stamp() -> str:
     """``YYYY-MM-DD HH:MM:SS`` (:2318-2327)."""
     return datetime.now().strftime("%Y-%m-%d %H:%M:%S")
@@ -424,6 +434,14 @@ class DataRegistration:
         self._overwrite_outputs = value
 
     # ----------------------------------------------------------------- resume helpers (:1346-1520)
+    def _entity_root(self, tile_id: str, round_id: str | None = None, bit_id: str | None = None) -> Path:
+        """``<fiducial root>/<tile>/<round>`` or ``<readouts root>/<tile>/<bit>`` (:1346-1376)."""
+        if (round_id is None) == (bit_id is None):
+            raise ValueError("Provide either round_id or bit_id, but not both.")
+        if round_id is not None:
+            return self._datastore._fiducial_root_path / Path(tile_id) / Path(round_id)
+        return self._datastore._readouts_root_path / Path(tile_id) / Path(bit_id)
+
     def _shape_of(self, tile_id: str, kind: str, round_id: str | None = None, bit_id: str | None = None):
         """Shape of a stored array or None.  The reference's store answers by path
         (``_image_shape(entity_root / kind)``, :1398-1402); an in-memory store by keys."""
@@ -431,9 +449,7 @@ class DataRegistration:
             raise ValueError("Provide either round_id or bit_id, but not both.")
         ds = self._datastore
         if hasattr(ds, "_fiducial_root_path"):
-            root = (ds._fiducial_root_path / Path(tile_id) / Path(round_id) if round_id is not None
-                    else ds._readouts_root_path / Path(tile_id) / Path(bit_id))
-            return ds._image_shape(root / Path(kind))
+            return ds._image_shape(self._entity_root(tile_id, round_id=round_id, bit_id=bit_id) / Path(kind))
         return ds._image_shape(tile=tile_id, round=round_id, bit=bit_id, kind=kind)
 
     def _has_valid_deconvolved_fiducial_image(self, tile_id: str | None = None, round_id: str | None = None) -> bool:

@@ -175,6 +175,19 @@ _SIGNATURES = {
     "m3d_moments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "m3d_normalized_sq_diff": (
         c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "m3d_filter_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "m3d_enforce_symmetric_boundary": (c_int, [c_void_p, _I3, _I3, _I3, c_void_p]),
+    "m3d_observed_region_mask": (c_int, [c_void_p, _I3, _I3, _I3, c_void_p]),
+    "m3d_pad_psf_workspace_bytes": (c_size_t, []),
+    "m3d_pad_psf": (c_int, [c_void_p, _I3, c_void_p, _I3, c_int, c_void_p, c_size_t, c_void_p]),
+    "m3d_kl_div_workspace_bytes": (c_size_t, []),
+    "m3d_kl_div": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, POINTER(ctypes.c_double),
+                           c_void_p]),
+    "m3d_fftconv_create": (c_int, [_I3, POINTER(c_void_p)]),
+    "m3d_fftconv_destroy": (c_int, [c_void_p]),
+    "m3d_fftconv_spectrum_bytes": (c_size_t, [c_void_p]),
+    "m3d_fftconv_otf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "m3d_fftconv_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     # include/m3d_io.h
     "m3d_blosc_info": (c_int, [c_void_p, c_size_t, POINTER(BloscHeader)]),
     "m3d_blosc_decode_host": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t]),

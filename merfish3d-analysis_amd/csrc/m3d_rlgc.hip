@@ -1074,4 +1074,211 @@ int m3d_clip_to_u16(const float *in, uint16_t *out, int64_t n, void *stream_v)
     return M3D_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// The solver's building blocks as stand-alone entry points (the reference exposes them as module-level
+// functions of utils/rlgc.py; m3d_rlgc_run runs fused versions of the same arithmetic).
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+__global__ void k_filter_update(const float *__restrict__ recon, const float *__restrict__ ht,
+                                const float *__restrict__ consensus, float *__restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = consensus[i] < 0.0f ? recon[i] : recon[i] * ht[i];
+}
+
+struct KlSums {
+    double A, B, T;
+};
+
+// kl_div (rlgc.py:382-412) as three raw sums: with a = (p + eps) m, b = (q + eps) m,
+// sum (a/A) (log(a/A) - log(b/B)) = T / A - log A + log B,  T = sum a (log a - log b) over a > 0
+// (masked-out terms are 0 * (-inf + inf) = NaN -> 0 in the reference).
+__global__ void k_kl_sums(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ mask,
+                          int64_t n, KlSums *__restrict__ partial)
+{
+    __shared__ double sm[4];
+    const float eps = 1e-4f;
+    double A = 0, B = 0, T = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mask ? mask[i] : 1.0f;
+        const float a = (p[i] + eps) * m, b = (q[i] + eps) * m;
+        A += a;
+        B += b;
+        if (a > 0.0f && b > 0.0f) T += (double)a * ((double)logf(a) - (double)logf(b));
+    }
+    A = block_sum(A, sm);
+    B = block_sum(B, sm);
+    T = block_sum(T, sm);
+    if (threadIdx.x == 0) {
+        KlSums r = {A, B, T};
+        partial[blockIdx.x] = r;
+    }
+}
+
+__global__ void k_kl_total(const KlSums *__restrict__ partial, int nblocks, double *__restrict__ out)
+{
+    __shared__ double sm[4];
+    double A = 0, B = 0, T = 0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) A += partial[i].A, B += partial[i].B, T += partial[i].T;
+    A = block_sum(A, sm);
+    B = block_sum(B, sm);
+    T = block_sum(T, sm);
+    if (threadIdx.x == 0) out[0] = (A > 0.0 && B > 0.0) ? T / A - log(A) + log(B) : 0.0;
+}
+
+int geo_from(const int32_t padded[3], const int32_t before[3], const int32_t after[3], Geo *g)
+{
+    M3D_REQUIRE(padded && before && after, "null shape");
+    for (int a = 0; a < 3; ++a)
+        M3D_REQUIRE(padded[a] > 0 && before[a] >= 0 && after[a] >= 0 && before[a] + after[a] < padded[a],
+                    "pad widths must leave an observed region");
+    g->Zp = padded[0], g->Yp = padded[1], g->Xp = padded[2];
+    g->bz = before[0], g->by = before[1], g->bx = before[2];
+    g->Z = padded[0] - before[0] - after[0], g->Y = padded[1] - before[1] - after[1];
+    g->X = padded[2] - before[2] - after[2];
+    g->Xc = g->Xp / 2 + 1;
+    g->N = (int64_t)g->Z * g->Y * g->X;
+    g->Np = (int64_t)g->Zp * g->Yp * g->Xp;
+    g->Nc = (int64_t)g->Zp * g->Yp * g->Xc;
+    return M3D_OK;
+}
+
+}  // namespace
+
+struct m3d_fftconv {
+    m3d::FftConvPlan *plan = nullptr;
+    int32_t shape[3] = {0, 0, 0};
+};
+
+extern "C" {
+
+int m3d_filter_update(const float *recon, const float *htratio, const float *consensus_map, float *out, int64_t n,
+                      void *stream)
+{
+    M3D_REQUIRE(recon && htratio && consensus_map && out && n >= 0, "null pointer");
+    if (n == 0) return M3D_OK;
+    hipLaunchKernelGGL(k_filter_update, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream, recon, htratio,
+                       consensus_map, out, n);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int m3d_enforce_symmetric_boundary(float *volume, const int32_t padded_zyx[3], const int32_t pad_before[3],
+                                   const int32_t pad_after[3], void *stream)
+{
+    M3D_REQUIRE(volume, "null pointer");
+    Geo g;
+    if (int rc = geo_from(padded_zyx, pad_before, pad_after, &g)) return rc;
+    hipLaunchKernelGGL(k_boundary, dim3(row_grid((int64_t)g.Zp * g.Yp)), dim3(64, kRowsPerBlock), 0,
+                       (hipStream_t)stream, volume, g);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int m3d_observed_region_mask(float *mask, const int32_t padded_zyx[3], const int32_t pad_before[3],
+                             const int32_t pad_after[3], void *stream)
+{
+    M3D_REQUIRE(mask, "null pointer");
+    Geo g;
+    if (int rc = geo_from(padded_zyx, pad_before, pad_after, &g)) return rc;
+    hipLaunchKernelGGL(k_mask, dim3(row_grid((int64_t)g.Zp * g.Yp)), dim3(64, kRowsPerBlock), 0, (hipStream_t)stream,
+                       mask, g);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+size_t m3d_pad_psf_workspace_bytes(void) { return sizeof(Status); }
+
+int m3d_pad_psf(const float *psf, const int32_t psf_zyx[3], float *out, const int32_t padded_zyx[3], int normalize,
+                void *work, size_t work_bytes, void *stream)
+{
+    M3D_REQUIRE(psf && psf_zyx && out && padded_zyx && work, "null pointer");
+    if (work_bytes < sizeof(Status)) {
+        m3d::set_err("workspace", "smaller than m3d_pad_psf_workspace_bytes()");
+        return M3D_ERR_WORKSPACE;
+    }
+    for (int a = 0; a < 3; ++a)
+        M3D_REQUIRE(psf_zyx[a] > 0 && psf_zyx[a] <= padded_zyx[a], "the PSF must fit the padded volume");
+    hipStream_t st = (hipStream_t)stream;
+    Geo g{};
+    g.Zp = padded_zyx[0], g.Yp = padded_zyx[1], g.Xp = padded_zyx[2];
+    const int64_t np = (int64_t)g.Zp * g.Yp * g.Xp, npsf = (int64_t)psf_zyx[0] * psf_zyx[1] * psf_zyx[2];
+    M3D_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)np * sizeof(float), st));
+    hipLaunchKernelGGL(k_psf_sum, dim3(1), dim3(kBlock), 0, st, psf, npsf, (Status *)work);
+    hipLaunchKernelGGL(k_psf_embed, dim3(grid_for(npsf)), dim3(kBlock), 0, st, psf, out, psf_zyx[0], psf_zyx[1],
+                       psf_zyx[2], g, (const Status *)work, normalize ? 1 : 0);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+size_t m3d_kl_div_workspace_bytes(void) { return sizeof(KlSums) * (size_t)kMaxGrid + sizeof(double); }
+
+int m3d_kl_div(const float *p, const float *q, const float *mask, int64_t n, void *work, size_t work_bytes,
+               double *result_host, void *stream)
+{
+    M3D_REQUIRE(p && q && work && result_host && n > 0, "null pointer or empty input");
+    if (work_bytes < m3d_kl_div_workspace_bytes()) {
+        m3d::set_err("workspace", "smaller than m3d_kl_div_workspace_bytes()");
+        return M3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    KlSums *partial = (KlSums *)((char *)work + sizeof(double));
+    double *total = (double *)work;
+    const int grid = grid_for(n, 4);
+    hipLaunchKernelGGL(k_kl_sums, dim3(grid), dim3(kBlock), 0, st, p, q, mask, n, partial);
+    hipLaunchKernelGGL(k_kl_total, dim3(1), dim3(kBlock), 0, st, partial, grid, total);
+    M3D_KERNEL_CHECK();
+    M3D_HIP_CHECK(hipMemcpyAsync(result_host, total, sizeof(double), hipMemcpyDeviceToHost, st));
+    M3D_HIP_CHECK(hipStreamSynchronize(st));  // the reference returns a Python float (rlgc.py:412)
+    return M3D_OK;
+}
+
+int m3d_fftconv_create(const int32_t shape_zyx[3], m3d_fftconv **out)
+{
+    M3D_REQUIRE(shape_zyx && out, "null pointer");
+    for (int a = 0; a < 3; ++a) M3D_REQUIRE(shape_zyx[a] > 0, "shape must be positive");
+    m3d::FftConvPlan *plan = nullptr;
+    const int rc = m3d::fftconv_create(shape_zyx[0], shape_zyx[1], shape_zyx[2], &plan);
+    if (rc) {
+        if (rc == M3D_ERR_UNSUPPORTED)
+            m3d::set_err("unsupported", "fused FFT engine: every axis must be 2^a 3^b and a pass must fit LDS");
+        return rc;
+    }
+    m3d_fftconv *h = new m3d_fftconv();
+    h->plan = plan;
+    for (int a = 0; a < 3; ++a) h->shape[a] = shape_zyx[a];
+    *out = h;
+    return M3D_OK;
+}
+
+int m3d_fftconv_destroy(m3d_fftconv *h)
+{
+    if (!h) return M3D_OK;
+    m3d::fftconv_destroy(h->plan);
+    delete h;
+    return M3D_OK;
+}
+
+size_t m3d_fftconv_spectrum_bytes(const m3d_fftconv *h)
+{
+    return h ? (size_t)m3d::fftconv_spectrum_elems(h->plan) * sizeof(float2) : 0;
+}
+
+int m3d_fftconv_otf(m3d_fftconv *h, const float *psf_padded, void *otf, void *stream)
+{
+    M3D_REQUIRE(h && psf_padded && otf, "null pointer");
+    return m3d::fftconv_make_otf(h->plan, psf_padded, (float2 *)otf, stream);
+}
+
+int m3d_fftconv_apply(m3d_fftconv *h, const float *image, const void *otf, int mode, void *scratch_spectrum, float *out,
+                      void *stream)
+{
+    M3D_REQUIRE(h && image && otf && scratch_spectrum && out, "null pointer");
+    M3D_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (H), 1 (conj H) or 2 (|H|^2)");
+    return m3d::fftconv_conv(h->plan, image, (const float2 *)otf, mode, (float2 *)scratch_spectrum, out, stream);
+}
+
 }  // extern "C"

@@ -25,6 +25,24 @@ def _diag(message: str, *, enabled: bool) -> None:
         print(f"[multiview-registration] {message}", flush=True)
 
 
+def _clear_cupy_memory(cp: Any = None) -> None:
+    """Release cached device allocations and FFT plans after a registration stage
+    (multiview_registration.py:33-54; the name is the reference's - there is no CuPy here: the caches are
+    torch's allocator and this package's rocFFT / engine plans)."""
+    import gc
+
+    import torch
+
+    from . import rlgc
+
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    rlgc.clear_rlgc_caches()
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
 def _to_device(array, gpu_id: int = 0):
     """(tensor in HBM, was_numpy).  uint16 / float32 keep their dtype, others -> float32."""
     import torch

@@ -147,6 +147,9 @@ def clear_rlgc_caches(clear_memory_pool: bool = False) -> None:
     for plan in _plan_cache.values():
         lib.m3d_rlgc_plan_destroy(plan.handle)
     _plan_cache.clear()
+    for engine in _fft_cache_3d.values():
+        engine.close()
+    _fft_cache_3d.clear()
     if clear_memory_pool:
         import torch
 
@@ -154,6 +157,218 @@ def clear_rlgc_caches(clear_memory_pool: bool = False) -> None:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------
+# the solver's building blocks as stand-alone device functions (rlgc.py:23-31, 203-412)
+#
+# ``rlgc`` / ``chunked_rlgc`` run fused versions of this arithmetic inside ``m3d_rlgc_run``; these keep the
+# reference's module-level names callable on their own.  Arrays: float32 torch tensors in HBM (NumPy arrays
+# are copied to the current device and the result comes back as NumPy, like the host-in / host-out solver).
+# ----------------------------------------------------------------------------
+def _dev_in(array, dtype=None):
+    """(tensor in HBM, came_from_numpy)"""
+    import torch
+
+    if isinstance(array, torch.Tensor):
+        if not array.is_cuda:
+            raise ValueError("expected a tensor in GPU memory (or a NumPy array)")
+        t = array if dtype is None or array.dtype == dtype else array.to(dtype)
+        return t.contiguous(), False
+    device = torch.device("cuda", torch.cuda.current_device())
+    return _as_device(np.asarray(array), device, dtype), True
+
+
+def _dev_out(tensor, as_numpy: bool):
+    return tensor.cpu().numpy() if as_numpy else tensor
+
+
+def _pads3(pad_width):
+    pads = [(int(a), int(b)) for a, b in pad_width]
+    if len(pads) != 3:
+        raise ValueError("pad_width must hold three (before, after) pairs")
+    return _hip.i3([p[0] for p in pads]), _hip.i3([p[1] for p in pads])
+
+
+def filter_update(recon, HTratio, consensus_map, out=None):
+    """Consensus-gated multiplicative update (``ElementwiseKernel`` of rlgc.py:23-31):
+    ``out = recon if consensus_map < 0 else recon * HTratio``."""
+    import torch
+
+    r, host = _dev_in(recon, torch.float32)
+    h, _ = _dev_in(HTratio, torch.float32)
+    c, _ = _dev_in(consensus_map, torch.float32)
+    if r.shape != h.shape or r.shape != c.shape:
+        raise ValueError("recon, HTratio and consensus_map must have the same shape")
+    res = torch.empty_like(r) if out is None else out
+    _hip.check(_hip.lib().m3d_filter_update(r.data_ptr(), h.data_ptr(), c.data_ptr(), res.data_ptr(), r.numel(),
+                                            _hip.current_stream(r.device)), "m3d_filter_update")
+    return _dev_out(res, host and out is None)
+
+
+def _symmetric_padded_axis_indices(length: int, pad_before: int, pad_after: int):
+    """Source indices of the left and right pad regions of one symmetrically extended axis (rlgc.py:203-227)."""
+    observed = np.arange(pad_before, length - pad_after, dtype=np.int64)
+    padded = np.pad(observed, (pad_before, pad_after), mode="symmetric")
+    return padded[:pad_before], padded[length - pad_after:]
+
+
+def enforce_symmetric_boundary(image, pad_width) -> None:
+    """Overwrite the pad regions with the symmetric extension of the observed region, in place
+    (rlgc.py:230-271; the three axis passes compose to one gather from the core)."""
+    import torch
+
+    if not (isinstance(image, torch.Tensor) and image.is_cuda and image.dtype == torch.float32
+            and image.is_contiguous() and image.dim() == 3):
+        raise ValueError("enforce_symmetric_boundary works in place on a contiguous float32 (Z, Y, X) tensor in HBM")
+    before, after = _pads3(pad_width)
+    _hip.check(_hip.lib().m3d_enforce_symmetric_boundary(image.data_ptr(), _hip.i3(image.shape), before, after,
+                                                         _hip.current_stream(image.device)),
+               "m3d_enforce_symmetric_boundary")
+
+
+def pad_psf(psf_temp, image_shape, normalize: bool = True):
+    """Zero-embed and centre a PSF in ``image_shape`` (the six rolls + ifftshift of rlgc.py:274-313), unit sum."""
+    import torch
+
+    psf, host = _dev_in(psf_temp, torch.float32)
+    if psf.dim() == 2:
+        psf = psf.unsqueeze(0).contiguous()
+    shape = tuple(int(v) for v in image_shape)
+    lib = _hip.lib()
+    out = torch.empty(shape, dtype=torch.float32, device=psf.device)
+    nbytes = int(lib.m3d_pad_psf_workspace_bytes())
+    work = torch.empty(nbytes, dtype=torch.uint8, device=psf.device)
+    _hip.check(lib.m3d_pad_psf(psf.data_ptr(), _hip.i3(psf.shape), out.data_ptr(), _hip.i3(shape), int(bool(normalize)),
+                               work.data_ptr(), nbytes, _hip.current_stream(psf.device)), "m3d_pad_psf")
+    return _dev_out(out, host)
+
+
+class TransferFunction:
+    """``rfftn`` of a padded PSF as the FFT engine keeps it (tiled, digit-reversed half spectrum in HBM).
+    Stands where the reference passes a complex64 array ``H`` to ``fft_conv``; ``conj()`` and ``abs2()`` give
+    the views rlgc.py:583-585 calls ``otfT`` and ``otfotfT`` (no data is copied: the Z pass conjugates /
+    squares on the fly)."""
+
+    def __init__(self, engine, spectrum, mode: int = 0):
+        self._engine, self._spectrum, self.mode = engine, spectrum, int(mode)
+
+    @property
+    def shape(self):
+        return self._engine.shape
+
+    def conj(self):
+        if self.mode == 2:
+            return self
+        return TransferFunction(self._engine, self._spectrum, 1 - self.mode)
+
+    def abs2(self):
+        return TransferFunction(self._engine, self._spectrum, 2)
+
+
+class _FFTConvEngine:
+    def __init__(self, shape, device):
+        import ctypes
+
+        import torch
+
+        self.shape = tuple(int(v) for v in shape)
+        self.device = device
+        self._lib = _hip.lib()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _hip.check(self._lib.m3d_fftconv_create(_hip.i3(self.shape), ctypes.byref(handle)), "m3d_fftconv_create")
+            self.handle = handle
+            self.spectrum_bytes = int(self._lib.m3d_fftconv_spectrum_bytes(handle))
+            self.scratch = torch.empty(self.spectrum_bytes, dtype=torch.uint8, device=device)
+
+    def close(self):
+        if self.handle:
+            self._lib.m3d_fftconv_destroy(self.handle)
+            self.handle = None
+
+
+# (device index, z, y, x) -> engine with its scratch spectrum: the reference's cached c64 buffer (rlgc.py:36, 341-346)
+_fft_cache_3d: dict[tuple[int, int, int, int], _FFTConvEngine] = {}
+
+
+def _engine_for(shape, device) -> _FFTConvEngine:
+    key = (int(device.index if device.index is not None else 0), *[int(v) for v in shape])
+    eng = _fft_cache_3d.get(key)
+    if eng is None:
+        eng = _fft_cache_3d[key] = _FFTConvEngine(shape, device)
+    return eng
+
+
+def transfer_function(psf_padded) -> TransferFunction:
+    """``cp.fft.rfftn(psf)`` of rlgc.py:582 for a PSF already padded and centred (``pad_psf``)."""
+    import torch
+
+    psf, _ = _dev_in(psf_padded, torch.float32)
+    eng = _engine_for(psf.shape, psf.device)
+    spectrum = torch.empty(eng.spectrum_bytes, dtype=torch.uint8, device=psf.device)
+    _hip.check(eng._lib.m3d_fftconv_otf(eng.handle, psf.data_ptr(), spectrum.data_ptr(), _hip.current_stream(psf.device)),
+               "m3d_fftconv_otf")
+    return TransferFunction(eng, spectrum)
+
+
+def fft_conv(image, H: TransferFunction, shape=None):
+    """``irfftn(rfftn(image) * H, s=shape)`` (rlgc.py:316-350) in five fused passes; ``H`` comes from
+    ``transfer_function`` (optionally ``.conj()`` / ``.abs2()``).  No clipping, float32 result."""
+    import torch
+
+    if not isinstance(H, TransferFunction):
+        raise TypeError("H must be a TransferFunction (see transfer_function): the engine keeps spectra in its own layout")
+    img, host = _dev_in(image, torch.float32)
+    if shape is not None and tuple(int(v) for v in shape) != tuple(img.shape):
+        raise ValueError("shape must equal image.shape")
+    if tuple(img.shape) != H.shape:
+        raise ValueError(f"image shape {tuple(img.shape)} does not match the transfer function's {H.shape}")
+    eng = H._engine
+    out = torch.empty_like(img)
+    _hip.check(eng._lib.m3d_fftconv_apply(eng.handle, img.data_ptr(), H._spectrum.data_ptr(), H.mode,
+                                          eng.scratch.data_ptr(), out.data_ptr(), _hip.current_stream(img.device)),
+               "m3d_fftconv_apply")
+    return _dev_out(out, host)
+
+
+def _observed_region_mask(shape, pad_width):
+    """float32 mask: 1 on the observed image, 0 in the padding (rlgc.py:353-379); a tensor on the current device."""
+    import torch
+
+    shape = tuple(int(v) for v in shape)
+    before, after = _pads3(pad_width)
+    mask = torch.empty(shape, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    _hip.check(_hip.lib().m3d_observed_region_mask(mask.data_ptr(), _hip.i3(shape), before, after,
+                                                   _hip.current_stream(mask.device)), "m3d_observed_region_mask")
+    return mask
+
+
+def kl_div(p, q, mask=None) -> float:
+    """Normalised, optionally masked Kullback-Leibler divergence with eps = 1e-4 and NaN terms dropped
+    (rlgc.py:382-412).  One device pass (three double-precision sums), one host read-back - the reference's
+    Python float."""
+    import ctypes
+
+    import torch
+
+    pt, _ = _dev_in(p, torch.float32)
+    qt, _ = _dev_in(q, torch.float32)
+    if pt.shape != qt.shape:
+        raise ValueError("p and q must have the same shape")
+    mt = None
+    if mask is not None:
+        mt, _ = _dev_in(mask, torch.float32)
+        if mt.shape != pt.shape:
+            raise ValueError("mask must have the shape of p")
+    lib = _hip.lib()
+    nbytes = int(lib.m3d_kl_div_workspace_bytes())
+    work = torch.empty(nbytes, dtype=torch.uint8, device=pt.device)
+    result = ctypes.c_double(0.0)
+    _hip.check(lib.m3d_kl_div(pt.data_ptr(), qt.data_ptr(), None if mt is None else mt.data_ptr(), pt.numel(),
+                              work.data_ptr(), nbytes, ctypes.byref(result), _hip.current_stream(pt.device)),
+               "m3d_kl_div")
+    return float(result.value)
 
 
 # ----------------------------------------------------------------------------
