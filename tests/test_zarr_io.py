@@ -238,3 +238,50 @@ def test_disk_backed_datastore_keeps_the_reference_layout(tmp_path):
     assert np.array_equal(got, flow) and attrs == {"map_stride_zyx_px": [4, 16, 16], "sofima_status": "ok"}
     assert (root / "fiducial" / "tile0001" / "round002" / "opticalflow_xform_px.ome.zarr").exists()
     assert store.load_local_sofima_flow_field(0, 1) is None
+
+
+def test_codec_round_trips_property():
+    """Randomised sizes, element widths, shuffles, block sizes and contents: the C codec and the NumPy
+    restatement decode each other's frames (hypothesis)."""
+    from hypothesis import given, settings, strategies as st
+
+    hip = pkg("_hip")
+    lib = hip.lib()
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.data())
+    def run(data):
+        T = data.draw(st.sampled_from([1, 2, 4, 8]))
+        n_el = data.draw(st.integers(min_value=1, max_value=5000))
+        shuffle = data.draw(st.sampled_from([0, 1, 2]))
+        codec = data.draw(st.sampled_from([4, 1]))
+        kind = data.draw(st.sampled_from(["random", "smooth", "zeros"]))
+        blocks = data.draw(st.sampled_from([0, 1, 2, 3, 7]))
+        rng = np.random.default_rng(data.draw(st.integers(0, 2**31)))
+        if kind == "random":
+            raw = rng.integers(0, 256, size=n_el * T, dtype=np.uint8)
+        elif kind == "zeros":
+            raw = np.zeros(n_el * T, dtype=np.uint8)
+        else:
+            raw = (np.cumsum(rng.integers(-2, 3, size=n_el)) + 1000).astype(f"<u{T}" if T > 1 else "u1").view(np.uint8)
+        nbytes = raw.size
+        blocksize = 0 if blocks == 0 else max(T, (nbytes // blocks) // T * T)
+        cap = lib.m3d_blosc_bound(nbytes, blocksize)
+        buf = np.zeros(cap, dtype=np.uint8)
+        got = ctypes.c_size_t(0)
+        hip.check(lib.m3d_blosc_encode_host(raw.ctypes.data, nbytes, T, 5, shuffle, codec, blocksize, buf.ctypes.data, cap,
+                                            ctypes.byref(got)))
+        frame = buf[: got.value].copy()
+        assert got.value <= cap
+        assert np.array_equal(blosc_ref.decode(frame), raw)
+        out = np.empty_like(raw)
+        hip.check(lib.m3d_blosc_decode_host(frame.ctypes.data, frame.size, out.ctypes.data, out.size))
+        assert np.array_equal(out, raw)
+        if codec == 4:
+            ref_frame = np.ascontiguousarray(blosc_ref.encode(raw, T, 5, shuffle, blocksize or 256 * 1024))
+            out[:] = 0
+            hip.check(lib.m3d_blosc_decode_host(ref_frame.ctypes.data, ref_frame.size, out.ctypes.data, out.size))
+            assert np.array_equal(out, raw)
+            assert np.array_equal(ref_frame, frame)          # same container bytes from both writers
+
+    run()
