@@ -44,7 +44,7 @@ class InMemoryDataStore:
         self.datastore_state = {}
         self._datastore_path = Path(datastore_path)
         self._segmentation_root_path = None
-        self.feature_predictor_folder_name = "ufish"
+        self.feature_predictor_folder_name = "feature_predictor"  # qi2labDataStore.py:1322
         self._corrected = {}      # (tile, "round"/"bit", id) -> array
         self._fiducial_decon = {}
         self._readout_decon = {}
@@ -303,7 +303,9 @@ class ZarrImageDataStore(InMemoryDataStore):
         self.fiducial_folder_name = "fiducial"
         self._fiducial_root_path = self._datastore_path / self.fiducial_folder_name
         self._readouts_root_path = self._datastore_path / "readouts"
-        for p in (self._fiducial_root_path, self._readouts_root_path):
+        self._feature_predictor_localizations_root_path = (
+            self._datastore_path / f"{self.feature_predictor_folder_name}_localizations")
+        for p in (self._fiducial_root_path, self._readouts_root_path, self._feature_predictor_localizations_root_path):
             p.mkdir(parents=True, exist_ok=True)
         self._corrected = _DiskImages(self, "corrected_data")
         self._fiducial_decon = _DiskImages(self, "decon_data")
@@ -380,6 +382,29 @@ class ZarrImageDataStore(InMemoryDataStore):
         fut = self._prefetched.pop(path, None)
         if fut is not None:
             fut.result()
+
+    # ---- predictor localisations: <root>/<predictor>_localizations/<tile>/<bit>.parquet (:5072-5130) ----
+    def _spots_path(self, tile, bit) -> Path:
+        return self._feature_predictor_localizations_root_path / self._tile(tile) / f"{self._bit(bit)}.parquet"
+
+    def save_local_feature_predictor_spots(self, spot_df, tile, bit, **_):
+        if self._tile(tile) is None or self._bit(bit) is None:
+            print("Set valid tile and bit ids")
+            return None
+        path = self._spots_path(tile, bit)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        self._save_to_parquet(spot_df, path)
+
+    @staticmethod
+    def _save_to_parquet(df, path) -> None:
+        df.to_parquet(path)
+
+    def load_local_feature_predictor_spots(self, tile, bit):
+        path = self._spots_path(tile, bit)
+        return pd.read_parquet(path) if path.exists() else None
+
+    def has_feature_predictor_spots(self, tile, bit) -> bool:
+        return self._tile(tile) is not None and self._bit(bit) is not None and self._spots_path(tile, bit).exists()
 
     def _flow_path(self, tile, round) -> Path:
         return self._fiducial_root_path / self._tile(tile) / self._round(round) / "opticalflow_xform_px"

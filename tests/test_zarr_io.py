@@ -238,6 +238,17 @@ def test_disk_backed_datastore_keeps_the_reference_layout(tmp_path):
     assert np.array_equal(got, flow) and attrs == {"map_stride_zyx_px": [4, 16, 16], "sofima_status": "ok"}
     assert (root / "fiducial" / "tile0001" / "round002" / "opticalflow_xform_px.ome.zarr").exists()
     assert store.load_local_sofima_flow_field(0, 1) is None
+    # predictor localisations as parquet; directory creation is idempotent
+    # (reference tests/test_datastore_feature_predictor.py:10-33)
+    import pandas as pd
+
+    spots = pd.DataFrame({"z": [1], "y": [2], "x": [3]})
+    assert not store.has_feature_predictor_spots(1, 2)
+    store.save_local_feature_predictor_spots(spots, tile="tile0001", bit="bit003")
+    store.save_local_feature_predictor_spots(spots, tile="tile0001", bit="bit003")
+    path = root / f"{store.feature_predictor_folder_name}_localizations" / "tile0001" / "bit003.parquet"
+    assert path.exists() and store.has_feature_predictor_spots(1, 2)
+    assert store.load_local_feature_predictor_spots(1, 2).equals(spots)
 
 
 def test_codec_round_trips_property():
