@@ -390,6 +390,7 @@ struct ChunkJob {
     int64_t oz, oy, ox;  // chunk origin in the volume
     uint32_t nbytes, blocksize;
     int shuffle;         // frame-level shuffle mode (0 also covers memcpyed frames)
+    uint32_t per_block;  // workgroups per Blosc block (set by the launchers)
 };
 
 // One thread = eight consecutive elements of one block.  T-byte elements, 8T rows per block.
@@ -397,11 +398,12 @@ template <int T>
 __global__ __launch_bounds__(256) void k_unshuffle_scatter(const uint8_t *__restrict__ stage, uint8_t *__restrict__ vol,
                                                            ChunkJob j)
 {
-    const uint32_t b = blockIdx.y;
+    // one-dimensional grid: `per_block` workgroups for each Blosc block (frames may hold many small blocks)
+    const uint32_t b = blockIdx.x / j.per_block;
     const uint32_t boff = b * j.blocksize;
     const uint32_t bsize = min(j.blocksize, j.nbytes - boff);
     const uint32_t ne = bsize / T, n8 = ne - ne % 8, nq = n8 / 8;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = (blockIdx.x % j.per_block) * blockDim.x + threadIdx.x;
     if (q * 8 >= ne) return;
     const int mode = effective_shuffle(j.shuffle, T, bsize);
     const uint8_t *src = stage + boff;
@@ -465,11 +467,12 @@ template <int T>
 __global__ __launch_bounds__(256) void k_gather_shuffle(const uint8_t *__restrict__ vol, uint8_t *__restrict__ stage,
                                                         ChunkJob j)
 {
-    const uint32_t b = blockIdx.y;
+    // one-dimensional grid: `per_block` workgroups for each Blosc block (frames may hold many small blocks)
+    const uint32_t b = blockIdx.x / j.per_block;
     const uint32_t boff = b * j.blocksize;
     const uint32_t bsize = min(j.blocksize, j.nbytes - boff);
     const uint32_t ne = bsize / T, n8 = ne - ne % 8, nq = n8 / 8;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = (blockIdx.x % j.per_block) * blockDim.x + threadIdx.x;
     if (q * 8 >= ne) return;
     const int mode = effective_shuffle(j.shuffle, T, bsize);
     uint8_t *dst = stage + boff;
@@ -509,18 +512,20 @@ __global__ __launch_bounds__(256) void k_gather_shuffle(const uint8_t *__restric
 }
 
 template <int T>
-void launch_unshuffle(const uint8_t *stage, uint8_t *vol, const ChunkJob &j, hipStream_t st)
+void launch_unshuffle(const uint8_t *stage, uint8_t *vol, ChunkJob j, hipStream_t st)
 {
     const uint32_t nblocks = (j.nbytes + j.blocksize - 1) / j.blocksize;
     const uint32_t groups = (j.blocksize / T + 7) / 8;
-    hipLaunchKernelGGL(k_unshuffle_scatter<T>, dim3((groups + 255) / 256, nblocks), dim3(256), 0, st, stage, vol, j);
+    j.per_block = (groups + 255) / 256;
+    hipLaunchKernelGGL(k_unshuffle_scatter<T>, dim3(j.per_block * nblocks), dim3(256), 0, st, stage, vol, j);
 }
 template <int T>
-void launch_shuffle(const uint8_t *vol, uint8_t *stage, const ChunkJob &j, hipStream_t st)
+void launch_shuffle(const uint8_t *vol, uint8_t *stage, ChunkJob j, hipStream_t st)
 {
     const uint32_t nblocks = (j.nbytes + j.blocksize - 1) / j.blocksize;
     const uint32_t groups = (j.blocksize / T + 7) / 8;
-    hipLaunchKernelGGL(k_gather_shuffle<T>, dim3((groups + 255) / 256, nblocks), dim3(256), 0, st, vol, stage, j);
+    j.per_block = (groups + 255) / 256;
+    hipLaunchKernelGGL(k_gather_shuffle<T>, dim3(j.per_block * nblocks), dim3(256), 0, st, vol, stage, j);
 }
 
 __global__ void k_zero_box(uint8_t *vol, ChunkJob j, int T)
@@ -545,6 +550,7 @@ ChunkJob job_for(const Grid &g, int64_t c)
     j.nbytes = (uint32_t)g.chunk_bytes;
     j.blocksize = (uint32_t)g.chunk_bytes;
     j.shuffle = 0;
+    j.per_block = 1;
     return j;
 }
 

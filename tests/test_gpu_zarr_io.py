@@ -99,6 +99,22 @@ def test_cblosc_frames_as_chunks(tmp_path, io_handle, golden):
         assert np.array_equal(out.cpu().numpy().ravel(), raw), name
 
 
+def test_frames_with_many_small_blocks(tmp_path, io_handle):
+    """A chunk stored as 70 000 sixteen-byte Blosc blocks (legal, if silly): the kernels index blocks along
+    one grid dimension, so the count is not limited to 65 535."""
+    hip, lib, handle = io_handle
+    rng = np.random.default_rng(9)
+    shape = (4, 350, 400)
+    vol = rng.integers(0, 4000, size=shape).astype(np.uint16)
+    d = tmp_path / "c" / "0" / "0"
+    d.mkdir(parents=True)
+    blosc_ref.encode(vol, 2, 1, 2, blocksize=16).tofile(d / "0")
+    out = torch.zeros(shape, dtype=torch.uint16, device=DEV)
+    hip.check(lib.m3d_zarr_read_device(handle, str(tmp_path / "c").encode(), hip.l3(shape), hip.l3(shape), 2,
+                                       out.data_ptr(), hip.current_stream(out.device), None))
+    assert np.array_equal(out.cpu().numpy(), vol)
+
+
 def test_image_store_round_trip_in_hbm(tmp_path):
     zio = pkg("zarr_io")
     rng = np.random.default_rng(6)
