@@ -426,17 +426,18 @@ def main() -> None:
         if stats["fused"] and stats["conv_calls"]:
             # the five kernels of one convolution, with the bytes each one actually has to move
             names = ("k_x_forward", "k_y_pass<fwd>", "k_z_conv", "k_y_pass<inv>", "k_x_inverse")
-            # B per padded voxel each kernel has to move (half-spectrum = 4 B / voxel), averaged
-            # over the two kinds of convolution in an iteration: input zero outside the core
-            # (2 of 4) and output read on the core only (2 of 4) - see ConvBox in m3d_fftconv.h
+            # B per padded voxel each pass has to move (half spectrum = 4 B / voxel), averaged over the four
+            # convolutions of an iteration (ConvBox in m3d_fftconv.h): estimate -> Hu (core rows in, mirrored in
+            # LDS, core out), the two ratio convolutions (core in, full out, sharing one dual X inverse pass that
+            # also runs the consensus product's X forward transform), consensus -> update (full in, core out)
             fz, fy, fx = (shape[i] / padded[i] for i in range(3))
             rows, vox = fz * fy, fz * fy * fx
             x_small = 4.0 * vox + 4.0 * rows   # real rows of the core <-> their half spectra
             y_small = 4.0 * rows + 4.0 * fz    # core z planes: core y rows <-> all ky
-            # (the estimate's convolution builds only the core planes in its Y pass and mirrors them in the
-            # Z pass's LDS, so three of the four forward Y passes are "small" and Z moves 5 fz + 7 on average)
-            moved = ((x_small + 8.0) / 2, (3.0 * y_small + 8.0) / 4, 5.0 * fz + 7.0, (y_small + 8.0) / 2,
-                     (x_small + 8.0) / 2)
+            x_dual = 8.0 + 4.0 + 4.0 + 4.0 * vox          # two spectra + update_norm in, product rows + HT sum out
+            x_update = 4.0 * rows + 3.0 * 4.0 * vox        # consensus rows + estimate + HT sum in, estimate out
+            moved = (3.0 * x_small / 4, (3.0 * y_small + 8.0) / 4, 5.0 * fz + 7.0, (y_small + 8.0) / 2,
+                     (x_small + x_dual + x_update) / 4)
             out["roofline_kernels"] = [
                 {"kernel": nme, "avg_ms": round(ms / stats["conv_calls"], 3),
                  "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
