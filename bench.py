@@ -122,7 +122,7 @@ def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
 
     # sized for roughly 10-30 s of host work.  The transforms (most of the time) run on all the host cores
     # this process may use (SciPy pocketfft workers); NumPy's elementwise passes are single-threaded.
-    cores = max(1, len(os.sched_getaffinity(0)))
+    cores = max(1, min(16, len(os.sched_getaffinity(0))))   # a one-GPU share of the host
     cz, cy, cx = min(tile_shape[0], 64), min(tile_shape[1], 256), min(tile_shape[2], 256)
     n_it, n_planes = 6, min(tile_shape[0], 16)
     crop = readout0[:cz, :cy, :cx].cpu().numpy()

@@ -175,7 +175,7 @@ class ImageIO:
     def __init__(self, num_threads: int | None = None):
         self._lib = _hip.lib()
         if num_threads is None:
-            num_threads = max(1, min(32, len(os.sched_getaffinity(0))))
+            num_threads = max(1, min(16, len(os.sched_getaffinity(0))))   # one GPU's share of the host cores
         handle = ctypes.c_void_p()
         _hip.check(self._lib.m3d_io_create(int(num_threads), ctypes.byref(handle)), "m3d_io_create")
         self._handle = handle
