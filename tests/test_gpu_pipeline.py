@@ -59,8 +59,8 @@ def _experiment(seed=0, zarr_root=None):
                   voxel_size_zyx_um=VOXEL)
     if zarr_root is None:
         store = ds_mod.InMemoryDataStore(**kwargs)
-    else:
-        store = ds_mod.ZarrImageDataStore(zarr_root, device="cuda:0", num_threads=4, **kwargs)
+    else:   # images as OME-Zarr, metadata as the reference's JSON sidecars / parquet tables
+        store = pkg("qi2lab_store").Qi2labDiskStore(zarr_root, device="cuda:0", num_threads=4, **kwargs)
     store.channel_psfs = [_psf((0.9, 1.2, 1.2)), _psf((0.9, 1.3, 1.3)), _psf((0.9, 1.4, 1.4))]
     shifts = {r: (0.0, 0.0, 0.0) if r == 0 else tuple(np.round(rng.uniform((-1, -4, -4), (1, 4, 4)), 0))
               for r in range(N_ROUNDS)}
@@ -140,6 +140,12 @@ def test_preprocess_then_decode_recovers_the_planted_transcripts(deformable, on_
     dec.decode_all_tiles(assign_to_cells=False, minimum_pixels=3, normalization_method="global",
                          target_gross_misid_rate=0.05)
     final = store.load_global_filtered_decoded_spots()
+    if on_disk:   # everything the run produced is on disk in the reference's layout; a fresh handle sees it
+        again = pkg("qi2lab_store").Qi2labDiskStore(tmp_path / "qi2lab")
+        assert again.load_local_round_transform_zyx_um("tile0001", "round003") is not None
+        assert again.load_global_filtered_decoded_spots().equals(final)
+        assert again.load_decode_normalization_vectors(None, "global")[0] is not None
+        assert (tmp_path / "qi2lab" / "readouts" / "tile0000" / "bit005" / "decon_data.ome.zarr" / "zarr.json").exists()
     assert len(final) > 0 and {"gene_id", "global_z", "global_y", "global_x", "distance_min", "cell_id"} <= set(final.columns)
     # planted transcripts of the overlap strip appear once in the truth per tile; de-duplicate them the same way
     truth_unique = truth.drop_duplicates(subset=["gene_id", "global_z", "global_y", "global_x"])
