@@ -12,13 +12,14 @@ files the reference writes:
 * ``readouts/<tile>/<bit>/attributes.json`` - ``round_linker``, wavelengths (:3083-3207, 3352-3530);
 * ``decoded[/<run>]/<tile>_decoded_features.parquet``, ``all_tiles_filtered_decoded_features[/<run>]/
   decoded_features.{parquet,csv.gz}``, ``<predictor>_localizations/<tile>/<bit>.parquet`` (:5347-5520);
-* every image as an OME-Zarr store through the I/O fast path (``ZarrImageDataStore`` / ``zarr_io``).
+* every image as an OME-Zarr store through the I/O fast path (``ZarrImageDataStore`` / ``zarr_io``), the
+  channel PSFs among them (``calibrations/psf_data/psf_NNN.ome.zarr`` + ``psf_manifest``, :698-745).
 
 Key names, value shapes, defaults and the print-and-return-``None`` convention for missing data follow the
 reference; ``tests/golden/qi2lab_sidecars.json`` holds a tree written and read back by the reference's own class
 (``tests/golden/make_golden_datastore.py``) and ``tests/test_datastore_sidecars.py`` checks both directions.
-Not covered (outside the hot path): PSF / shading / noise-map calibration images, fused and segmentation
-products, store validation.
+Not covered (outside the hot path): shading / noise-map calibration images, fused and segmentation products,
+store validation.
 """
 
 from __future__ import annotations
@@ -180,6 +181,46 @@ class Qi2labDiskStore(ZarrImageDataStore):
     @property
     def num_rounds(self):
         return len(self.round_ids)
+
+    @property
+    def channel_psfs(self):
+        """PSFs of ``calibrations/psf_data/psf_NNN.ome.zarr`` in manifest order: one stacked array when they
+        share a shape, else a list (:677-696, 2518-2540); None when the store has none."""
+        psfs = getattr(self, "_psfs", None)
+        if psfs is None:
+            manifest = self._load_calibrations_attributes().get("psf_manifest")
+            root = self._datastore_path / "calibrations" / "psf_data"
+            if isinstance(manifest, dict) and manifest:
+                ids = [manifest[k]["id"] for k in sorted(manifest, key=int)]
+            elif root.exists():
+                ids = sorted(p.name[: -len(".ome.zarr")] for p in root.glob("psf_*.ome.zarr"))
+            else:
+                ids = []
+            if not ids:
+                return None
+            psfs = self._psfs = [np.asarray(self._io.read_image(root / i), dtype=np.float32) for i in ids]
+        if len({tuple(p.shape) for p in psfs}) == 1:
+            return np.stack(psfs, axis=0)
+        return psfs
+
+    @channel_psfs.setter
+    def channel_psfs(self, value):
+        if value is None:      # the in-memory base class initialises the attribute
+            return
+        if isinstance(value, np.ndarray) and value.dtype != object:
+            psf_list = [np.asarray(value[i], dtype=np.float32) for i in range(value.shape[0])] if value.ndim >= 3 \
+                else [np.asarray(value, dtype=np.float32)]
+        else:
+            psf_list = [np.asarray(psf, dtype=np.float32) for psf in list(value)]
+        if not psf_list:
+            raise ValueError("channel_psfs cannot be empty.")
+        self._psfs = psf_list
+        root = self._datastore_path / "calibrations" / "psf_data"
+        manifest = {}
+        for idx, psf in enumerate(psf_list):
+            self._io.write_image(root / f"psf_{idx:03d}", psf)
+            manifest[str(idx)] = {"id": f"psf_{idx:03d}", "shape_zyx": list(psf.shape)}
+        self._set_calibration_attribute("psf_manifest", manifest)
 
     def load_chromatic_affine_transforms_zyx_um(self) -> dict:
         calibration = self._load_calibrations_attributes().get("chromatic_affine_transforms_zyx_um", {})

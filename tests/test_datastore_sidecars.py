@@ -166,3 +166,24 @@ def test_operators_see_the_in_memory_helpers_too(tmp_path):
     assert ds.load_local_sofima_flow_field(0, 1)[1] == {"sofima_status": "ok"}
     # image-level attributes are part of the entity's metadata (reference: _load_entity_attributes)
     assert ds._load_entity_attributes(ds._fiducial_root_path / "tile0000" / "round002")["sofima_status"] == "ok"
+
+
+def test_channel_psfs_live_in_the_calibrations_folder(tmp_path):
+    qs = pkg("qi2lab_store")
+    cb = _frame(FIXTURE["loads"]["codebook"])
+    ds = qs.Qi2labDiskStore(tmp_path / "s", num_tiles=1, num_rounds=1, num_bits=4, codebook=cb)
+    assert ds.channel_psfs is None
+    rng = np.random.default_rng(1)
+    psfs = rng.uniform(size=(3, 5, 7, 7)).astype(np.float32)
+    ds.channel_psfs = psfs
+    manifest = json.loads((tmp_path / "s" / "calibrations" / "attributes.json").read_text())["psf_manifest"]
+    assert manifest == {str(i): {"id": f"psf_{i:03d}", "shape_zyx": [5, 7, 7]} for i in range(3)}   # :736-741
+    assert (tmp_path / "s" / "calibrations" / "psf_data" / "psf_002.ome.zarr" / "0" / "zarr.json").exists()
+    again = qs.Qi2labDiskStore(tmp_path / "s")
+    assert np.array_equal(again.channel_psfs, psfs)
+    ragged = [psfs[0], psfs[1][:, :5, :5]]
+    again.channel_psfs = ragged
+    got = qs.Qi2labDiskStore(tmp_path / "s").channel_psfs
+    assert isinstance(got, list) and len(got) == 2 and np.array_equal(got[1], ragged[1])
+    with pytest.raises(ValueError):
+        again.channel_psfs = []
