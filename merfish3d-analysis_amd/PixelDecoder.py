@@ -114,15 +114,13 @@ def _join_gpu_workers(processes, label: str) -> None:
 
 
 def _open_datastore(datastore_path):
-    """Re-open the on-disk store inside a worker (PixelDecoder.py:262); boundary component."""
-    try:
-        from merfish3danalysis.qi2labDataStore import qi2labDataStore
-    except ImportError as exc:  # pragma: no cover - needs the reference's storage package
-        raise RuntimeError(
-            "multi-process decoding re-opens the datastore by path and needs the qi2labDataStore "
-            "package; with an in-memory datastore run one process per GPU under torch.distributed"
-        ) from exc
-    return qi2labDataStore(datastore_path, validate=False)
+    """Re-open the on-disk store inside a worker (PixelDecoder.py:262-270): this package's reader of the
+    reference's directory layout, images loaded straight into the worker's GPU."""
+    from .qi2lab_store import Qi2labDiskStore
+
+    torch = _torch()
+    device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else None
+    return Qi2labDiskStore(datastore_path, device=device)
 
 
 def decode_tiles_worker(datastore_path, tile_indices, gpu_id, merfish_bits, verbose, decode_mode,

@@ -312,6 +312,23 @@ class ZarrImageDataStore(InMemoryDataStore):
         self._readout_decon = _DiskImages(self, "decon_data")
         self._predictor = _DiskImages(self, f"{self.feature_predictor_folder_name}_data")
 
+    # a spawned per-GPU worker receives the operator (and with it this store) by pickle
+    # (DataRegistration.py:2151-2154): the reader handle, its staging and the read-ahead thread are rebuilt there
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_io_threads"] = self._io.num_threads
+        for key in ("_io", "_prefetch_pool", "_prefetch_io", "_prefetch_stream"):
+            state[key] = None
+        state["_prefetched"] = {}
+        return state
+
+    def __setstate__(self, state):
+        from . import zarr_io
+
+        threads = state.pop("_io_threads", None)
+        self.__dict__.update(state)
+        self._io = zarr_io.ImageIO(num_threads=threads)
+
     def _image_shape(self, tile, round=None, bit=None, kind="corrected_data"):
         """By keys like the in-memory store, or - the reference's form (qi2labDataStore.py:1835-1862) -
         by the logical image path ``<entity root>/<image name>``."""

@@ -187,3 +187,18 @@ def test_channel_psfs_live_in_the_calibrations_folder(tmp_path):
     assert isinstance(got, list) and len(got) == 2 and np.array_equal(got[1], ragged[1])
     with pytest.raises(ValueError):
         again.channel_psfs = []
+
+
+def test_store_survives_pickling_into_a_worker(tmp_path):
+    import pickle
+
+    qs = pkg("qi2lab_store")
+    cb = _frame(FIXTURE["loads"]["codebook"])
+    ds = qs.Qi2labDiskStore(tmp_path / "s", num_tiles=1, num_rounds=1, num_bits=4, codebook=cb, num_threads=2)
+    img = np.random.default_rng(0).integers(90, 300, size=(4, 20, 24)).astype(np.uint16)
+    ds.set_corrected_image(img, tile=0, round=0)
+    clone = pickle.loads(pickle.dumps(ds))
+    assert clone._io is not ds._io and clone._io.num_threads == 2
+    assert np.array_equal(clone.load_local_corrected_image(0, round=0, return_future=False), img)
+    clone.save_local_round_transform_zyx_um(np.eye(4), tile=0, round=0)
+    assert ds.load_local_round_transform_zyx_um(0, 0) is not None            # same files

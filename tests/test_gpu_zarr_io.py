@@ -169,3 +169,37 @@ def test_tile_read_ahead_hands_over_the_same_images(tmp_path):
     store.set_corrected_image(imgs[(0, 0)][0] + 7, tile=0, bit=0)                     # invalidates the read-ahead
     assert np.array_equal(store.load_local_readout_image(0, bit=0, return_future=False).cpu().numpy(), imgs[(0, 0)][0] + 7)
     torch.cuda.synchronize()
+
+
+def test_decode_worker_reopens_the_datastore_by_path(tmp_path):
+    """decode_tiles_worker (the per-GPU child of decode_all_tiles, PixelDecoder.py:207-309) gets a path, not an
+    object: it must find images, normalisation vectors and linkers on disk and leave its tables there."""
+    PD, qs = pkg("PixelDecoder"), pkg("qi2lab_store")
+    from helpers import codebook_frame
+
+    rng = np.random.default_rng(12)
+    bits = np.array([[1, 1, 1, 1, 0, 0], [0, 0, 1, 1, 1, 1], [1, 1, 0, 0, 1, 1]], dtype=np.int64)
+    store = qs.Qi2labDiskStore(tmp_path / "ds", device=DEV, num_tiles=2, num_rounds=1, num_bits=6,
+                               codebook=codebook_frame(bits, ["g0", "g1", "Blank-0"]))
+    shape = (6, 64, 64)
+    for t in range(2):
+        store.set_stage_position_zyx_um(t, (0.0, 10.0 * t, 0.0))
+        pos = rng.integers((1, 6, 6), (5, 58, 58), size=(12, 3))
+        code = rng.integers(0, 2, size=12)
+        for b in range(6):
+            vol = rng.normal(100, 3, size=shape)
+            for (z, y, x), c in zip(pos, code):
+                if bits[c, b]:
+                    vol[z - 1:z + 2, y - 2:y + 3, x - 2:x + 3] += 900
+            store.set_corrected_image(np.clip(vol, 0, 65535).astype(np.uint16), tile=t, bit=b)
+            store.save_local_feature_predictor_image(np.ones(shape, dtype=np.float32), tile=t, bit=b)
+            store.set_round_linker(t, b, 1)
+        store.save_local_round_transform_zyx_um(np.eye(4, dtype=np.float32), tile=t, round=0)
+    for kind in ("global", "iterative"):   # the worker loads both, as the reference's does (:272-277)
+        store.save_decode_normalization_vectors(None, kind, np.full(6, 900.0, np.float32), np.full(6, 100.0, np.float32))
+    PD.decode_tiles_worker(tmp_path / "ds", [0, 1], 0, 6, 0, "auto", (3, 1, 1), (0.5, 10.0), 3, 0.1, "global")
+    fresh = qs.Qi2labDiskStore(tmp_path / "ds")
+    for t in range(2):
+        table = fresh.load_local_decoded_spots(tile=t)
+        assert table is not None and len(table) >= 8 and set(table["gene_id"]) <= {"g0", "g1", "Blank-0"}
+        assert (table["tile_idx"] == t).all()
