@@ -654,6 +654,23 @@ class PixelDecoder:
             p = (np.asarray(camera_to_stage_affine) @ np.array([*list(p), 1]))[:-1]
         return (np.array(affine) @ np.array([*list(p), 1]))[:-1]
 
+    @staticmethod
+    def _warp_pixels(points, spacing, origin, affine, camera_to_stage_affine=None):
+        """``_warp_pixel`` for every row of ``points`` (the reference loops in Python, :3134-3143).  Same
+        operations in the same order per point - one float64 matrix-vector product per affine - with the
+        array construction hoisted out of the loop, so the results are bit-identical."""
+        out = np.empty((points.shape[0], 3), dtype=np.float64)
+        phys = points * spacing + origin
+        A = np.array(affine).astype(np.float64, copy=False)
+        C = None if camera_to_stage_affine is None else np.asarray(camera_to_stage_affine).astype(np.float64, copy=False)
+        v = np.ones(4, dtype=np.float64)
+        for i in range(points.shape[0]):
+            v[:3] = phys[i]
+            if C is not None:
+                v[:3] = (C @ v)[:-1]
+            out[i] = (A @ v)[:-1]
+        return out
+
     def _decoded_z_to_source_z(self, decoded_z):
         return float(self._z_range[0]) + decoded_z
 
@@ -729,10 +746,8 @@ class PixelDecoder:
         df["tile_z"] = np.round(df["z"], 0).astype(int)
         df["tile_y"] = np.round(df["y"], 0).astype(int)
         df["tile_x"] = np.round(df["x"], 0).astype(int)
-        pts = df[["z", "y", "x"]].to_numpy()
-        for i in range(pts.shape[0]):
-            pts[i, :] = self._warp_pixel(pts[i, :].copy(), self._spacing, self._origin, self._affine,
-                                         self._camera_to_stage_affine)
+        pts = self._warp_pixels(df[["z", "y", "x"]].to_numpy(), self._spacing, self._origin, self._affine,
+                                self._camera_to_stage_affine)
         df["global_z"] = np.round(pts[:, 0], 2)
         df["global_y"] = np.round(pts[:, 1], 2)
         df["global_x"] = np.round(pts[:, 2], 2)
