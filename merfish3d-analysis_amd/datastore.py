@@ -1,13 +1,13 @@
-"""In-memory stand-in for the qi2labDataStore duck-type the tile operators talk to.
+"""Datastores for the tile operators: the qi2labDataStore duck-type at three levels.
 
-The reference's on-disk store (``qi2labDataStore.py``, OME-NGFF zarr3 + JSON + parquet) is
-the drop-in *boundary* and is not re-implemented: the
-operators in this package accept any object with the same properties / ``load_*`` /
-``save_*`` methods.  This class provides exactly those methods on top of dictionaries so the
-operators can be exercised (tests, ``bench.py``) without zarr/tensorstore - the same role
-the ``SimpleNamespace`` / dataclass fakes play in the reference's own tests
-(``tests/test_chromatic_estimator.py:9-27``).  Arrays may be NumPy arrays or torch tensors
-already in HBM (then nothing crosses PCIe when an operator loads them).
+* ``InMemoryDataStore`` - every method the operators call, on dictionaries: tests and ``bench.py`` run
+  without touching a disk (the role the ``SimpleNamespace`` / dataclass fakes play in the reference's own
+  tests, ``tests/test_chromatic_estimator.py:9-27``).  Arrays may be NumPy arrays or torch tensors already in
+  HBM (then nothing crosses PCIe when an operator loads them).
+* ``ZarrImageDataStore`` - the same with every image on disk as an OME-Zarr store in the reference's folder
+  layout, read and written through the I/O fast path (``zarr_io``), with next-tile read-ahead.
+* ``qi2lab_store.Qi2labDiskStore`` (its own module) - additionally the reference's JSON sidecars and parquet
+  tables, i.e. a directory the reference's ``qi2labDataStore`` class can open and vice versa.
 """
 
 from __future__ import annotations
