@@ -127,7 +127,7 @@ def _rfftn(x):
 
 
 def _irfftn(x, shape):
-    return sfft.irfftn(x, s=shape, workers=FFT_WORKERS) if FFT_WORKERS > 0 else np.fft.irfftn(x, s=shape)
+    return sfft.irfftn(x, s=shape, axes=tuple(range(-len(shape), 0)), workers=FFT_WORKERS) if FFT_WORKERS > 0 else np.fft.irfftn(x, s=shape, axes=tuple(range(-len(shape), 0)))
 
 
 def fft_conv(image: np.ndarray, H: np.ndarray, shape) -> np.ndarray:
