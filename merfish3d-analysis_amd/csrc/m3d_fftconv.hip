@@ -29,6 +29,12 @@ using namespace m3d;
 
 // loads kept in flight per thread in the load phase of each pass (measured on MI355X)
 #ifndef M3D_KU_Z
+#ifndef M3D_ZREG_ATTR
+#define M3D_ZREG_ATTR
+#endif
+#ifndef M3D_ZREG_OTF_EARLY
+#define M3D_ZREG_OTF_EARLY 0
+#endif
 #ifndef M3D_KH_Z
 #define M3D_KH_Z 16
 #endif
@@ -54,6 +60,7 @@ struct FftConvPlan {
     size_t lds_x, lds_y, lds_z;
     int rset_x, rset_y, rset_z;  // 1: lean kernels (no radix 16 / 8 stage on that axis)
     int ythreads, zthreads, xthreads, gx, gy, gz, dual_rows, dual_threads, zmirror;
+    int zreg;  // Zp / 16 when the register variant of the Z pass applies (Zp = 32, 64, 128, 256), else 0
 };
 
 }  // namespace m3d
@@ -596,6 +603,106 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
         if (live && z >= g.out.z0 && z < g.out.z0 + g.out.nz) col[(int64_t)z * g.plane] = lds_z[(z << g.lP) + p];
 }
 
+// ---------------------------------------------------------------- Z pass, register variant (Zp = 16 L)
+// The 7-barrier LDS transform chain of k_z_conv is what bounds it (all four Z passes of an iteration take the same
+// time whatever they move).  For Zp = 16 L, L in {2, 4, 8, 16}: thread (p, l) owns the 16 samples z = l + L m of
+// column p and transforms them in registers (16-point DFT), one LDS exchange hands thread (p, l) the L partial
+// results of frequencies k1 = l, l + L, ... for an L-point DFT across l, the transfer function is applied in
+// registers, and the same steps run backwards: two barriers and four LDS passes per tile.  With
+//   z = l + L m, k = k1 + 16 k2:  W_N^(z k) = W_16^(m k1) * W_N^(l k1) * W_L^(l k2).
+// Spectra never leave the kernel, so only the OTF's plane order matters: natural (plane k holds frequency k), written
+// by this kernel's own mode -1.
+template <int L>
+__global__ __launch_bounds__(16 * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__restrict__ spec, const float2 *__restrict__ otf,
+                                                       ConvGeo g, const float2 *__restrict__ tw, int mode, float scale)
+{
+    constexpr int N = 16 * L, P = 16;
+    constexpr int KS = L * P + P;  // stride between k1 slabs, padded by one row of columns: conflict-free both ways
+    constexpr int NBF = 16 / L;    // (k1, column) groups per thread in the cross-thread step
+    __shared__ float2 ex[16 * KS];
+    const int tid = threadIdx.x, p = tid & (P - 1), l = tid >> 4;
+    const int64_t p0 = (int64_t)blockIdx.x * P;
+    const bool live = p0 + p < g.plane;
+    const int64_t pc = live ? p0 + p : g.plane - 1;
+    float2 *col = spec + pc;
+    const int zin_hi = g.in.z0 + g.in.nz;
+
+    float2 h[16];  // transfer function at k = (l + b L) + 16 k2
+    if (M3D_ZREG_OTF_EARLY && mode >= 0) {  // requested before anything else
+#pragma unroll
+        for (int b = 0; b < NBF; ++b)
+#pragma unroll
+            for (int k2 = 0; k2 < L; ++k2) h[b * L + k2] = otf[pc + (int64_t)((l + b * L) + 16 * k2) * g.plane];
+    }
+    float2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int z = l + L * m;
+        const bool inside = z >= g.in.z0 && z < zin_hi;
+        // outside the input's planes: zero, or (zmirror) the plane it mirrors - the same data again, never zero
+        const int zs = inside ? z : (g.zmirror ? sym_src(z, g.in.z0, g.in.nz) : g.in.z0);
+        v[m] = col[(int64_t)zs * g.plane];
+        if (!live || !(inside || g.zmirror)) v[m] = make_float2(0.f, 0.f);
+    }
+    float2 w[16];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) w[k1] = tw[l * k1];  // W_N^(l k1), l k1 < N
+    dft16<false>(v);
+    ex[l * P + p] = v[0];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) ex[k1 * KS + l * P + p] = cmul(v[k1], w[k1]);
+    if (!M3D_ZREG_OTF_EARLY && mode >= 0) {  // requested once the 16 samples are out of the registers
+#pragma unroll
+        for (int b = 0; b < NBF; ++b)
+#pragma unroll
+            for (int k2 = 0; k2 < L; ++k2) h[b * L + k2] = otf[pc + (int64_t)((l + b * L) + 16 * k2) * g.plane];
+    }
+    __syncthreads();
+    float2 y[16];
+#pragma unroll
+    for (int b = 0; b < NBF; ++b) {
+        const int k1 = l + b * L;
+#pragma unroll
+        for (int ll = 0; ll < L; ++ll) y[b * L + ll] = ex[k1 * KS + ll * P + p];
+        dft_r<L, false>(&y[b * L]);  // X[k1 + 16 k2] at y[b L + k2]
+    }
+    if (mode < 0) {
+#pragma unroll
+        for (int b = 0; b < NBF; ++b)
+#pragma unroll
+            for (int k2 = 0; k2 < L; ++k2)
+                if (live) col[(int64_t)((l + b * L) + 16 * k2) * g.plane] = y[b * L + k2];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float2 hh = h[i];
+        if (mode == 1) hh.y = -hh.y;
+        if (mode == 2) hh = make_float2(hh.x * hh.x + hh.y * hh.y, 0.0f);
+        const float2 t = cmul(y[i], hh);
+        y[i] = make_float2(t.x * scale, t.y * scale);
+    }
+#pragma unroll
+    for (int b = 0; b < NBF; ++b) {
+        const int k1 = l + b * L;
+        dft_r<L, true>(&y[b * L]);  // sum over k2: partial result for lane l' at y[b L + l']
+        // each thread rewrites exactly the slots it read: no barrier needed in between
+#pragma unroll
+        for (int ll = 0; ll < L; ++ll)
+            ex[k1 * KS + ll * P + p] = cmul_conj(y[b * L + ll], tw[ll * k1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = ex[k1 * KS + l * P + p];
+    dft16<true>(v);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int z = l + L * m;
+        if (live && z >= g.out.z0 && z < g.out.z0 + g.out.nz) col[(int64_t)z * g.plane] = v[m];
+    }
+}
+
+
 bool factor_23(int n, int *radix, int *nstages, bool z_axis = false)
 {
     int c3 = 0, c2 = 0, m = n;
@@ -726,6 +833,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->gy = knob("M3D_FFT_GY", 4);
     p->gz = knob("M3D_FFT_GZ", 4);
     p->zmirror = knob("M3D_FFT_ZMIRROR", 1) ? 1 : 0;
+    p->zreg = (knob("M3D_FFT_ZREG", 1) && (Zp == 32 || Zp == 64 || Zp == 128 || Zp == 256)) ? Zp / 16 : 0;
     p->dual_rows = knob("M3D_FFT_DUAL_ROWS", 2);
     p->dual_threads = knob("M3D_FFT_DUAL_T", 256);
     p->ythreads = knob("M3D_FFT_YT", 768);
@@ -821,6 +929,27 @@ static int row_groups(const FftConvPlan *p, const m3d::ConvBox &b)
     return (b.y0 + b.ny - yg0 + p->RB - 1) / p->RB;
 }
 
+// One Z pass (mode -1: forward only, OTF construction) with the kernel family the plan uses throughout.
+static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, const ConvGeo &g, int mode, float scale,
+                     hipStream_t st)
+{
+    const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
+    if (p->zreg) {
+        const unsigned nb16 = (unsigned)((p->plane + 15) / 16);
+        switch (p->zreg) {
+        case 2: hipLaunchKernelGGL(k_z_conv_reg<2>, dim3(nb16), dim3(32), 0, st, spec, otf, g, p->az.tw, mode, scale); break;
+        case 4: hipLaunchKernelGGL(k_z_conv_reg<4>, dim3(nb16), dim3(64), 0, st, spec, otf, g, p->az.tw, mode, scale); break;
+        case 8: hipLaunchKernelGGL(k_z_conv_reg<8>, dim3(nb16), dim3(128), 0, st, spec, otf, g, p->az.tw, mode, scale); break;
+        default: hipLaunchKernelGGL(k_z_conv_reg<16>, dim3(nb16), dim3(256), 0, st, spec, otf, g, p->az.tw, mode, scale); break;
+        }
+    } else if (p->rset_z == 2)
+        hipLaunchKernelGGL(k_z_conv<2>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    else if (p->rset_z)
+        hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    else
+        hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+}
+
 static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
                              EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                              const ConvBox *mirror_box = nullptr, float2 *spec_alt = nullptr)
@@ -870,13 +999,7 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
     int rc = launch_forward_xy(p, psf_padded, otf, st);
     if (rc) return rc;
     const ConvGeo g = geo_of(p);
-    const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
-    if (p->rset_z == 2)
-        hipLaunchKernelGGL(k_z_conv<2>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
-    else if (p->rset_z)
-        hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
-    else
-        hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, otf, (const float2 *)nullptr, g, p->az, -1, 1.0f);
+    launch_z(p, otf, (const float2 *)nullptr, g, -1, 1.0f, st);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -903,13 +1026,7 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     ConvGeo g = geo_of(p, (mirrored && p->zmirror) ? mirror_box : in_box, out_box);
     g.zmirror = (mirrored && p->zmirror) ? 1 : 0;
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
-    const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
-    if (p->rset_z == 2)
-        hipLaunchKernelGGL(k_z_conv<2>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
-    else if (p->rset_z)
-        hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
-    else
-        hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    launch_z(p, spec, otf, g, mode, scale, st);
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
     if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<true, 1>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
