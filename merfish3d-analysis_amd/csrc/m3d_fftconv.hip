@@ -5,13 +5,18 @@
 //   k_x_forward   two real rows -> one packed complex FFT (in LDS) -> two Hermitian half rows,
 //                 written into the tiled spectrum  S[z][kx/TW][y][kx%TW]      (r 4 B, w 4 B)
 //   k_y_pass      FFT along y of one contiguous [Yp][TW] column tile, in place  (r 4 B, w 4 B)
-//   k_z_conv      FFT along z, multiply by the OTF (or conj / |.|^2), inverse FFT along z,
-//                 in place; P adjacent spectrum positions per block             (r 8 B, w 4 B)
+//   k_z_conv_reg  (Zp = 32, 64, 128, 256) FFT along z, multiply by the OTF (or conj / |.|^2), inverse FFT
+//                 along z, in place, 32 adjacent spectrum positions per block: 16-point DFTs in registers
+//                 around one LDS exchange per direction                          (r 8 B, w 4 B)
+//   k_z_conv      the same for every other 2^a 3^b length, as an in-LDS stage chain
 //   k_y_pass      inverse                                                        (r 4 B, w 4 B)
 //   k_x_inverse   two Hermitian half rows -> packed complex inverse FFT -> two real rows
 //                                                                                (r 4 B, w 4 B)
-// The spectrum keeps the digit-reversed order of the decimation-in-frequency passes along
-// y and z (see m3d_fft.h) - only the OTF, which went through the same passes, ever meets it.
+// The spectrum keeps the digit-reversed order of the decimation-in-frequency passes along y (and along z
+// in k_z_conv; k_z_conv_reg keeps z natural) - only the OTF, which went through the same passes of the
+// same plan, ever meets it.  Further kernels: k_y_forward_mirror (Y pass of a symmetric extension given by
+// its core rows), k_x_inverse_dual (two results that meet in the consensus arithmetic share one X inverse
+// pass, optionally chained into the next convolution's X forward pass), fused tails (ConvEpilogue).
 // Replaces cp.fft.rfftn / "*= H" / cp.fft.irfftn of fft_conv (utils/rlgc.py:316-350).
 
 #include "m3d_fftconv.h"
