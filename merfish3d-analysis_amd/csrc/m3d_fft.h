@@ -35,6 +35,10 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifndef M3D_TW_POWERS
+#define M3D_TW_POWERS 1
+#endif
+
 struct AxisPlan {
     int n;                 // transform length (2^a 3^b)
     int nstages;
@@ -251,8 +255,37 @@ __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estrid
             j = 0;
         }
         float2 w[R];
+        // Twiddles W^(j q): a few table loads, the other powers one or two complex products away (<= 2 extra
+        // roundings each) - the loads go through an L1 that the streaming traffic of the pass keeps evicting,
+        // and a stage waits for them.  M3D_TW_POWERS: 0 = every power from the table, 1 = 1,2,4 from the table
+        // (radix 9), 2 = only the first from the table.
+        const int j1 = j * twstep;
+        if constexpr (R == 9 && M3D_TW_POWERS == 1) {
+            w[1] = tw[j1];
+            w[2] = tw[2 * j1];
+            w[4] = tw[4 * j1];
+            w[3] = cmul(w[1], w[2]);
+            w[5] = cmul(w[1], w[4]);
+            w[6] = cmul(w[2], w[4]);
+            w[7] = cmul(w[3], w[4]);
+            w[8] = cmul(w[4], w[4]);
+        } else if constexpr (R == 9 && M3D_TW_POWERS == 2) {
+            w[1] = tw[j1];
+            w[2] = cmul(w[1], w[1]);
+            w[4] = cmul(w[2], w[2]);
+            w[3] = cmul(w[1], w[2]);
+            w[5] = cmul(w[1], w[4]);
+            w[6] = cmul(w[2], w[4]);
+            w[7] = cmul(w[3], w[4]);
+            w[8] = cmul(w[4], w[4]);
+        } else if constexpr ((R == 3 || R == 4) && M3D_TW_POWERS >= 1) {
+            w[1] = tw[j1];
+            w[2] = cmul(w[1], w[1]);
+            if constexpr (R == 4) w[3] = cmul(w[1], w[2]);
+        } else {
 #pragma unroll
-        for (int q = 1; q < R; ++q) w[q] = tw[j * q * twstep];
+            for (int q = 1; q < R; ++q) w[q] = tw[q * j1];
+        }
         float2 *p0 = data + (size_t)(blk * M + j) * estride + (size_t)(bg * G) * bstride;
         // interleaved layouts (bstride == 1): lanes 8 apart sit 256 B apart = same LDS banks;
         // rotating the member each lane starts with makes every access conflict free
