@@ -651,9 +651,22 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
         v[m] = col[(int64_t)zs * g.plane];
         if (!live || !(inside || g.zmirror)) v[m] = make_float2(0.f, 0.f);
     }
-    float2 w[16];
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) w[k1] = tw[l * k1];  // W_N^(l k1), l k1 < N
+    float2 w[16];  // W_N^(l k1), l k1 < N: powers 1, 2, 4, 8 from the table, the rest by products
+    w[1] = tw[l];
+    w[2] = tw[2 * l];
+    w[4] = tw[4 * l];
+    w[8] = tw[8 * l];
+    w[3] = cmul(w[1], w[2]);
+    w[5] = cmul(w[1], w[4]);
+    w[6] = cmul(w[2], w[4]);
+    w[7] = cmul(w[3], w[4]);
+    w[9] = cmul(w[1], w[8]);
+    w[10] = cmul(w[2], w[8]);
+    w[11] = cmul(w[3], w[8]);
+    w[12] = cmul(w[4], w[8]);
+    w[13] = cmul(w[5], w[8]);
+    w[14] = cmul(w[6], w[8]);
+    w[15] = cmul(w[7], w[8]);
     dft16<false>(v);
     ex[l * P + p] = v[0];
 #pragma unroll
@@ -694,9 +707,17 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
         const int k1 = l + b * L;
         dft_r<L, true>(&y[b * L]);  // sum over k2: partial result for lane l' at y[b L + l']
         // each thread rewrites exactly the slots it read: no barrier needed in between
+        float2 u[L];  // W_N^(ll k1): powers 1, 2, 4, 8 of W^k1 from the table (ll k1 < N), the rest by products
+        u[0] = make_float2(1.0f, 0.0f);
 #pragma unroll
-        for (int ll = 0; ll < L; ++ll)
-            ex[k1 * KS + ll * P + p] = cmul_conj(y[b * L + ll], tw[ll * k1]);
+        for (int ll = 1; ll < L; ++ll) {
+            if ((ll & (ll - 1)) == 0)
+                u[ll] = tw[ll * k1];
+            else
+                u[ll] = cmul(u[ll & (ll - 1)], u[ll & -ll]);  // highest bits x lowest set bit
+        }
+#pragma unroll
+        for (int ll = 0; ll < L; ++ll) ex[k1 * KS + ll * P + p] = cmul_conj(y[b * L + ll], u[ll]);
     }
     __syncthreads();
 #pragma unroll
