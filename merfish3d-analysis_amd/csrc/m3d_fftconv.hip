@@ -84,9 +84,13 @@ struct ConvGeo {
     int zmirror;           // the spectrum holds the box's z planes only; the Z pass mirrors them in LDS
 };
 
+// z is uniform per block in every caller: keeping its term apart leaves one 64-bit product per block and 32-bit
+// arithmetic per element (nT * Yp * TW < 2^31 is checked when the plan is made)
 __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, int k)
 {
-    return ((((int64_t)z * g.nT + (k >> g.lTW)) * g.Yp + y) << g.lTW) + (k & (g.TW - 1));
+    const int64_t zterm = (int64_t)z * g.plane;  // plane = nT * Yp * TW
+    const int in_plane = (((k >> g.lTW) * g.Yp + y) << g.lTW) + (k & (g.TW - 1));
+    return zterm + in_plane;
 }
 
 // One tile per block; several blocks share a CU (LDS 16-70 KB each) so the load / transform /
@@ -872,6 +876,10 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     }
     p->nT = (p->Xc + p->TW - 1) / p->TW;
     p->plane = (int64_t)p->nT * Yp * p->TW;
+    if (p->plane >= (int64_t)1 << 31) {  // spec_index keeps in-plane offsets in 32 bits
+        delete p;
+        return M3D_ERR_UNSUPPORTED;
+    }
 
     // tables: twiddles for x, y, z + pos for x
     const size_t nb = sizeof(float2) * ((size_t)Xp + Yp + Zp) + sizeof(int) * (size_t)Xp;
