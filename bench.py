@@ -1,53 +1,76 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mvoxels/s through decon + decode on synthetic MERFISH tiles.
 
-One *step* = the per-tile hot path on one synthetic tile held in HBM:
-B x RLGC deconvolution of the readout images (one per bit, clip -> uint16 like
-DataRegistration.py:993-995) followed by one full ``PixelDecoder.decode_one_tile``
-(readout x predictor, low-pass, fused pixel decode, connected components, transcript
-table).  Default workload = BASELINE.json ``configs[1]``: 64 x 2048 x 2048 tile, 22-bit /
-140-codeword codebook, PSF 64 x 51 x 51 (FFT volume 128 x 2187 x 2187).
+One *step* = the per-tile hot path on one synthetic tile held in HBM.
 
-    python bench.py --gpus 1 --steps 1 --warmup 1
+``--workload config2`` (default, BASELINE.json ``configs[1]``): B x RLGC deconvolution of the readout
+images (one per bit, clip -> uint16 like DataRegistration.py:993-995) followed by one full
+``PixelDecoder.decode_one_tile`` (readout x predictor, low-pass, fused pixel decode, connected components,
+transcript table) on a 64 x 2048 x 2048 tile, 22-bit / 140-codeword codebook, PSF 64 x 51 x 51 (FFT volume
+128 x 2187 x 2187).  Every rank works on its own tile per step: weak scaling, no data-path collective.
+
+``--workload config3`` (``configs[2]``): a volume of ``--tiles`` such tiles with 11 rounds each, dealt to the
+ranks in contiguous ranges (PixelDecoder.py:4811-4820, DataRegistration.py:2139-2156): per tile 11 fiducial
+deconvolutions, 10 x ``register_pair_to_fixed`` against round 1, 22 readout deconvolutions and
+``decode_one_tile`` warping every bit with its round's transform.  The tile count is fixed as N grows:
+strong scaling.  Tiles are synthesised outside the timed regions (one region per tile, device-synchronised
+on both sides), so the inputs are resident in HBM whenever the clock runs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Tiles are independent: every rank decodes its own tile per step (weak scaling, no
-data-path collective; RCCL is only used for the timing barrier / max-reduce here).
-Rank 0 prints ONE JSON line.  ``roofline`` prices one RLGC iteration (the unit that is launched
-~1600 times per tile) at SURVEY.md section 8(d)'s 148 algorithmic bytes per padded voxel over the
-iteration's device time measured with HIP events inside ``m3d_rlgc_run``; ``roofline_conv`` and
-``roofline_kernels`` break it down, ``roofline_decode`` is the MFMA-bound decode kernel.
+**Wall budget.**  A config-2 tile takes tens of seconds, so ``--steps`` / ``--warmup`` are upper bounds under a
+wall-clock budget counted from process start (``M3D_BENCH_WALL_S``, default 450 s): the first (untimed) tile is
+timed, the number of timed tiles that fit is derived from it, and the JSON reports ``steps`` = tiles actually
+timed next to ``steps_requested``.  The CPU baseline, the decode-kernel timing and the I/O leg run *before* the
+timed loop, and rank 0 prints a complete JSON line after every timed tile (the last line wins), so a killed run
+still leaves a parsed record.
+
+``roofline`` prices one RLGC iteration (the unit that is launched ~1600 times per tile) at SURVEY.md section
+8(d)'s 148 algorithmic bytes per padded voxel over the iteration's device time measured with HIP events inside
+``m3d_rlgc_run``; ``roofline_conv`` and ``roofline_kernels`` break it down, ``roofline_decode`` is the MFMA-bound
+decode kernel.
 """
 
 from __future__ import annotations
 
-import argparse
-import importlib
-import itertools
-import json
-import os
-import sys
 import time
-from pathlib import Path
 
-import numpy as np
-import pandas as pd
-import torch
+_T_IMPORT0 = time.time()   # the wall budget counts from here (or from the launching parent's start)
+
+import argparse  # noqa: E402
+import importlib  # noqa: E402
+import itertools  # noqa: E402
+import json  # noqa: E402
+import os  # noqa: E402
+import socket  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+from pathlib import Path  # noqa: E402
+
+import numpy as np  # noqa: E402
+import pandas as pd  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 WORKLOADS = {
-    # name: (tile zyx, bits, psf zyx, emitters)
-    "config2": ((64, 2048, 2048), 22, (64, 51, 51), 80_000),
-    "config1": ((16, 256, 256), 16, (16, 51, 51), 1_200),
+    # name: (tile zyx, bits, psf zyx, emitters, rounds)
+    "config2": ((64, 2048, 2048), 22, (64, 51, 51), 80_000, 1),
+    "config1": ((16, 256, 256), 16, (16, 51, 51), 1_200, 1),
+    "config3": ((64, 2048, 2048), 22, (64, 51, 51), 80_000, 11),
+    "config3_small": ((16, 256, 256), 16, (16, 51, 51), 1_200, 8),   # rehearsal size of config3
 }
+CONFIG_INDEX = {"config1": 0, "config2": 1, "config3": 2, "config3_small": 2}
 RLGC_ALGORITHMIC_BYTES_PER_ITER_VOXEL = 148.0
 RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL = 20.0  # 2 FFTs x 8 B + OTF read 4 B
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+DEFAULT_WALL_BUDGET_S = 450.0
 
 
 def hw4_codebook(n_bits: int, n_codes: int = 140, n_blank: int = 10, seed: int = 0) -> pd.DataFrame:
@@ -83,8 +106,12 @@ def gaussian_psf(shape, sigma, device):
     return (psf / psf.sum()).to(torch.float32).contiguous()
 
 
-def make_tile(shape, bits_matrix, n_emitters, seed, device, kernels):
-    """uint16 readouts + float32 predictor images of one synthetic tile, generated in HBM."""
+def make_tile(shape, bits_matrix, n_emitters, seed, device, kernels, round_shifts_px=None, n_beads=0):
+    """uint16 readouts + float32 predictor images of one synthetic tile, generated in HBM.
+
+    ``round_shifts_px`` (config 3): one (dz, dy, dx) per round; bit b belongs to round ``b * R // B`` and its
+    readout / predictor images are the round-1-frame images displaced by that round's shift (trilinear
+    resample), and a fiducial bead volume per round is returned as well."""
     gen = torch.Generator(device=device).manual_seed(seed)
     C, B = bits_matrix.shape
     z = torch.randint(2, shape[0] - 2, (n_emitters,), device=device, generator=gen)
@@ -93,30 +120,56 @@ def make_tile(shape, bits_matrix, n_emitters, seed, device, kernels):
     code = torch.randint(0, C, (n_emitters,), device=device, generator=gen)
     amp = (torch.rand(n_emitters, device=device, generator=gen) * 600 + 300) / 0.0138  # 300-900 peak photons
     on = torch.from_numpy(bits_matrix).to(device)[code]  # [E, B]
-    readouts, predictors = [], []
+    readouts, predictors, fiducials = [], [], []
     scratch = torch.empty(shape, dtype=torch.float32, device=device)
+    n_rounds = len(round_shifts_px) if round_shifts_px is not None else 1
+
+    def displaced(vol, r):
+        # content of the round-1 frame seen in round r: sample at x - shift (pull offset = -shift)
+        if round_shifts_px is None or not any(round_shifts_px[r]):
+            return vol
+        off = [-float(v) for v in round_shifts_px[r]]
+        return kernels.affine_warp(vol, np.eye(3), off, shape, mode="nearest")
+
     for b in range(B):
+        r = b * n_rounds // B
         sel = on[:, b] > 0
         vol = torch.zeros(shape, dtype=torch.float32, device=device)
         jitter = torch.rand(int(sel.sum()), device=device, generator=gen) * 0.4 + 0.8
         vol.index_put_((z[sel], y[sel], x[sel]), amp[sel] * jitter, accumulate=True)
         kernels.gaussian_lowpass(vol, (1.8, 1.6, 1.6), True, out=vol, scratch=scratch)  # PSF blur
+        vol = displaced(vol, r)
         vol += 100.0
         img = torch.poisson(vol, generator=gen).clamp_(0, 65535).to(torch.uint16)
         readouts.append(img)
         pred = torch.zeros(shape, dtype=torch.float32, device=device)
         pred.index_put_((z[sel], y[sel], x[sel]), torch.ones(int(sel.sum()), device=device), accumulate=True)
         kernels.gaussian_lowpass(pred, (1.0, 1.2, 1.2), True, out=pred, scratch=scratch)
+        pred = displaced(pred, r)
         pred.mul_(1.0 / 0.0441)  # blob peak -> 1
         pred += torch.rand(shape, device=device, generator=gen) * 0.02  # predictor floor (never exactly 0)
         pred.clamp_(0.0, 1.0)
         predictors.append(pred)
         del vol
+    if round_shifts_px is not None:
+        nb = int(n_beads)
+        bz = torch.randint(2, shape[0] - 2, (nb,), device=device, generator=gen)
+        by = torch.randint(8, shape[1] - 8, (nb,), device=device, generator=gen)
+        bx = torch.randint(8, shape[2] - 8, (nb,), device=device, generator=gen)
+        bamp = (torch.rand(nb, device=device, generator=gen) * 2000 + 2000) / 0.0138
+        base = torch.zeros(shape, dtype=torch.float32, device=device)
+        base.index_put_((bz, by, bx), bamp, accumulate=True)
+        kernels.gaussian_lowpass(base, (1.8, 1.6, 1.6), True, out=base, scratch=scratch)
+        for r in range(n_rounds):
+            vol = displaced(base, r).clone()
+            vol += 100.0
+            fiducials.append(torch.poisson(vol, generator=gen).clamp_(0, 65535).to(torch.uint16))
+            del vol
     truth = torch.stack([code, z, y, x], dim=1).cpu().numpy()
-    return readouts, predictors, truth
+    return readouts, predictors, truth, fiducials
 
 
-def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
+def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit, rlgc_calls_per_tile=None):
     """Oracle (NumPy/SciPy/C restatement) timed on a bounded crop of the same workload."""
     from oracle import ccl_ref, decode_ref, rlgc_ref
 
@@ -155,7 +208,8 @@ def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
                              0.6058, minimum_pixels=3)
     t_dec = time.perf_counter() - t0
     n_tile = float(np.prod(tile_shape))
-    tile_seconds = n_bits * max(iters_per_bit, 1.0) * per_vox_iter * np_full + t_dec * n_tile / float(n_planes * cy * cx)
+    calls = n_bits if rlgc_calls_per_tile is None else rlgc_calls_per_tile
+    tile_seconds = calls * max(iters_per_bit, 1.0) * per_vox_iter * np_full + t_dec * n_tile / float(n_planes * cy * cx)
     return {
         "value": n_tile / tile_seconds / 1e6,
         "unit": "Mvoxels/s",
@@ -164,24 +218,27 @@ def cpu_baseline(readout0, psf, bits_matrix, tile_shape, n_bits, iters_per_bit):
         "sample": (f"oracle RLGC (scipy.fft on {cores} threads, NumPy elementwise passes and Generator.binomial on one) {info.iterations} "
                    f"iterations on a {cz}x{cy}x{cx} crop (FFT volume "
                    f"{'x'.join(str(v) for v in info.padded_shape)}, {t_rl:.1f}s) + oracle low-pass/decode/extract on "
-                   f"{n_planes}x{cy}x{cx}x{n_bits} bits ({t_dec:.1f}s), extrapolated linearly to {n_bits} bits x "
+                   f"{n_planes}x{cy}x{cx}x{n_bits} bits ({t_dec:.1f}s), extrapolated linearly to {calls} deconvolutions x "
                    f"{iters_per_bit:.1f} iterations on the full tile"),
     }
 
 
 def pmc_traffic(padded_shape, key="rlgc_iteration_hbm_bytes"):
     """HBM bytes per RLGC iteration (or per fft_conv launch) from the committed rocprofv3 PMC
-    passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/r01_pmc_rlgc_traffic.json, made by
+    passes (FETCH_SIZE x 2 + WRITE_SIZE, profiles/rNN_pmc_rlgc_traffic.json, made by
     scripts/pmc_summary.py) - only for the FFT volume they were collected on, else None.  PMC
     collection needs its own profiler passes, so this figure is measured offline, not in this run."""
-    path = Path(__file__).resolve().parent / "profiles" / "r01_pmc_rlgc_traffic.json"
-    try:
-        d = json.loads(path.read_text())
-    except (OSError, ValueError):
-        return None
-    if abs(d.get("padded_volume_bytes", 0) - 4.0 * float(np.prod(padded_shape))) > 1:
-        return None
-    return round(float(d[key]), 1) if d.get(key) else None
+    for path in sorted((Path(__file__).resolve().parent / "profiles").glob("r*_pmc_rlgc_traffic.json"),
+                       reverse=True):
+        try:
+            d = json.loads(path.read_text())
+        except (OSError, ValueError):
+            continue
+        if abs(d.get("padded_volume_bytes", 0) - 4.0 * float(np.prod(padded_shape))) > 1:
+            continue
+        if d.get(key):
+            return round(float(d[key]), 1)
+    return None
 
 
 def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tuple[float, float]:
@@ -199,7 +256,35 @@ def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tu
     return float(t.item()), float(it.item())
 
 
-def io_leg(readouts, predictors, n_bits, step_seconds, voxels, sample_bits=4):
+def agree_min(value: int, world: int, device) -> int:
+    """The same integer on every rank: the minimum of the ranks' proposals (step counts must agree)."""
+    if world <= 1:
+        return int(value)
+    import torch.distributed as dist
+
+    if dist.get_backend() != "nccl":
+        device = torch.device("cpu")
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def steps_that_fit(requested: int, seconds_per_step: float, seconds_left: float, margin: float = 1.08) -> int:
+    """How many of ``requested`` steps fit into ``seconds_left`` (at least one: a bench that times nothing
+    reports nothing)."""
+    if seconds_per_step <= 0:
+        return max(1, int(requested))
+    return max(1, min(int(requested), int(seconds_left / (seconds_per_step * margin))))
+
+
+def contiguous_share(n_items: int, world: int, rank: int) -> range:
+    """Contiguous range of ``n_items`` for ``rank`` (the reference's chunking, PixelDecoder.py:4811-4820)."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def io_leg(readouts, predictors, n_bits, sample_bits=4):
     """Datastore image I/O beside the compute: a sample of the tile's readout (uint16) and
     predictor (float32) images is written as OME-Zarr / Blosc-zstd stores and loaded back into HBM through
     ``zarr_io.ImageIO`` (zstd on host threads, bit shuffle + scatter on the GPU); per-tile figures are the
@@ -240,25 +325,57 @@ def io_leg(readouts, predictors, n_bits, step_seconds, voxels, sample_bits=4):
         "host_threads": threads, "round_trip_equal": bool(ok),
         "read_GBps": round(raw / t_read / 1e9, 2), "write_GBps": round(raw / t_write / 1e9, 2),
         "compression_ratio": round(raw / max(files, 1), 2),
-        "load_seconds_per_tile": round(load_tile, 3),
-        "value_including_load": round(voxels / (step_seconds + load_tile) / 1e6, 4), "unit": "Mvoxels/s",
+        "load_seconds_per_tile": round(load_tile, 3), "unit": "Mvoxels/s",
     }
 
 
-def main() -> None:
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """``bench.py --gpus N`` started plainly: start N ranks with torch.distributed.run as a CHILD process and
+    pass its output and exit code on.  The parent has made no GPU call (``device_count`` does not initialise
+    HIP on this image) and never execs."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env["M3D_BENCH_T0"] = repr(_T_IMPORT0)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve()), *argv]
+    print(f"[bench] WORLD_SIZE unset and --gpus {n}: starting {n} ranks: {' '.join(cmd[1:8])} ...",
+          file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
+    ap.add_argument("--tiles", type=int, default=8, help="config3: tiles of the volume (fixed as N grows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])
+
+    t_origin = float(os.environ.get("M3D_BENCH_T0", _T_IMPORT0))
+    budget = float(os.environ.get("M3D_BENCH_WALL_S", DEFAULT_WALL_BUDGET_S))
+
+    def seconds_left() -> float:
+        return budget - (time.time() - t_origin)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: every requested GPU needs its own rank")
     # M3D_BENCH_BACKEND=gloo is a rehearsal switch (several ranks sharing one GPU on a one-GPU box,
     # which RCCL refuses); the measured configuration is always one rank per GPU over RCCL
     backend = os.environ.get("M3D_BENCH_BACKEND", "nccl")
@@ -272,54 +389,121 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"only {dist.get_world_size()} of {args.gpus} ranks joined")
 
     import __graft_entry__  # noqa: F401  (puts the repo root on sys.path)
 
     kernels = importlib.import_module("merfish3d-analysis_amd.kernels")
     rl = importlib.import_module("merfish3d-analysis_amd.utils.rlgc")
+    mv = importlib.import_module("merfish3d-analysis_amd.utils.multiview_registration")
     PD = importlib.import_module("merfish3d-analysis_amd.PixelDecoder")
     DS = importlib.import_module("merfish3d-analysis_amd.datastore")
+    scoring = importlib.import_module("merfish3d-analysis_amd.scoring")
 
-    shape, n_bits, psf_shape, n_emitters = WORKLOADS[args.workload]
+    shape, n_bits, psf_shape, n_emitters, n_rounds = WORKLOADS[args.workload]
+    strong = n_rounds > 1   # config 3: a fixed volume of tiles dealt to the ranks
     codebook = hw4_codebook(n_bits)
     bits_matrix = codebook.iloc[:, 1:].to_numpy(dtype=np.int64)
     psf = gaussian_psf(psf_shape, (1.8, 1.6, 1.6), device)
-    readouts, predictors, truth = make_tile(shape, bits_matrix, n_emitters, 1 + rank, device, kernels)
-    print(f"[bench] rank {rank}: synthetic tile ready", file=sys.stderr, flush=True)
+    n_tile = float(np.prod(shape))
+    pads = rl.pad_widths_zyx(shape, psf_shape)
+    padded = [s + a + b for s, (a, b) in zip(shape, pads)]
+    np_full = float(np.prod(padded))
+    spacing = (0.315, 0.098, 0.098)
+    rlgc_calls_per_tile = n_bits + (n_rounds if strong else 0)
 
-    store = DS.InMemoryDataStore(num_tiles=1, num_rounds=1, num_bits=n_bits, codebook=codebook)
-    for b in range(n_bits):
-        store.set_corrected_image(readouts[b], tile=0, bit=b)
-        store.save_local_feature_predictor_image(predictors[b], tile=0, bit=b)
+    store = DS.InMemoryDataStore(num_tiles=1, num_rounds=n_rounds, num_bits=n_bits, codebook=codebook,
+                                 voxel_size_zyx_um=spacing)
     decoder = PD.PixelDecoder(store, merfish_bits=n_bits, verbose=0)
     decon = torch.empty(shape, dtype=torch.float32, device=device)
-    stats = {"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "fused": True,
-             "kernel_ms": [0.0] * 5, "loop_ms": 0.0}
+    stats: dict = {}
+
+    def reset_stats() -> None:
+        stats.update({"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "fused": True,
+                      "kernel_ms": [0.0] * 5, "loop_ms": 0.0, "reg_s": 0.0, "reg_calls": 0, "reg_err_px": 0.0})
+
+    reset_stats()
     t_start = time.perf_counter()
 
     def progress(msg: str) -> None:  # keeps the GPU box's silence watchdog fed
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
+    def tile_shifts(tile_seed: int):
+        """config 3: per-round shifts <= (1, 4, 4) px, round 1 at rest."""
+        rng = np.random.default_rng(tile_seed)
+        s = rng.uniform(-1.0, 1.0, size=(n_rounds, 3)) * np.asarray([1.0, 4.0, 4.0])
+        s[0] = 0.0
+        return np.round(s, 2)
+
+    current = {}
+
+    def load_tile(tile_seed: int) -> None:
+        """Synthesise one tile in HBM and put it into the store (outside every timed region)."""
+        current.clear()
+        store._readout_decon.clear()
+        store._fiducial_decon.clear()
+        store._round_xform.clear()
+        shifts = tile_shifts(tile_seed) if strong else None
+        readouts, predictors, truth, fiducials = make_tile(
+            shape, bits_matrix, n_emitters, tile_seed, device, kernels, round_shifts_px=shifts,
+            n_beads=max(300, int(n_tile / 3.5e5)))
+        for b in range(n_bits):
+            store.set_corrected_image(readouts[b], tile=0, bit=b)
+            store.save_local_feature_predictor_image(predictors[b], tile=0, bit=b)
+            store.set_round_linker(store.tile_ids[0], store.bit_ids[b], 1 + b * n_rounds // n_bits)
+        for r, f in enumerate(fiducials):
+            store.set_corrected_image(f, tile=0, round=store.round_ids[r])
+        current.update(readouts=readouts, predictors=predictors, truth=truth, fiducials=fiducials, shifts=shifts)
+        torch.cuda.synchronize(device)
+
+    def deconvolve(image, profile: bool):
+        _o, info = rl.rlgc_device(image, psf, rng_seed=42, out=decon, profile=profile)
+        stats["iters"] += info.iterations
+        stats["conv_ms"] += info.conv_ms_total
+        stats["conv_calls"] += info.conv_calls
+        stats["loop_ms"] += info.loop_ms
+        stats["fused"] = info.fused_engine
+        for k in range(5):
+            stats["kernel_ms"][k] += info.kernel_ms[k] if info.kernel_ms else 0.0
+        return kernels.clip_to_u16(decon), info
+
+    def register_rounds(profile: bool) -> None:
+        """DataRegistration._process_fiducial_rounds_on_gpu (:456-558) with the volumes staying in HBM."""
+        t = store.tile_ids[0]
+        reference, _ = deconvolve(current["fiducials"][0], profile)
+        store.save_local_round_transform_zyx_um(np.eye(4, dtype=np.float32), tile=t, round=store.round_ids[0])
+        for r in range(1, n_rounds):
+            moving, info = deconvolve(current["fiducials"][r], profile)
+            t0 = time.perf_counter()
+            T = mv.register_pair_to_fixed(reference, moving, spacing_zyx_um=spacing)
+            stats["reg_s"] += time.perf_counter() - t0
+            stats["reg_calls"] += 1
+            store.save_local_round_transform_zyx_um(np.asarray(T, dtype=np.float32), tile=t, round=store.round_ids[r])
+            # moving = reference displaced by +shift => pull transform = -shift ... in the generator's
+            # convention the content sits at x + shift, so the pull offset is +shift
+            err = np.abs(T[:3, 3] / np.asarray(spacing) - current["shifts"][r]).max()
+            stats["reg_err_px"] = max(stats["reg_err_px"], float(err))
+            progress(f"round {r + 1}/{n_rounds}: {info.iterations} RLGC iterations, shift error {err:.3f} px")
+
     def deconvolve_bits(profile: bool) -> None:
         for b in range(n_bits):  # DataRegistration._apply_bits_on_gpu: decon -> clip -> uint16
-            _o, info = rl.rlgc_device(readouts[b], psf, rng_seed=42, out=decon, profile=profile)
-            stats["iters"] += info.iterations
-            stats["conv_ms"] += info.conv_ms_total
-            stats["conv_calls"] += info.conv_calls
-            stats["loop_ms"] += info.loop_ms
-            stats["fused"] = info.fused_engine
-            for k in range(5):
-                stats["kernel_ms"][k] += info.kernel_ms[k]
-            store.save_local_deconvolved_readout_image(kernels.clip_to_u16(decon), tile=0, bit=b)
+            u16, info = deconvolve(current["readouts"][b], profile)
+            store.save_local_deconvolved_readout_image(u16, tile=0, bit=b)
             progress(f"bit {b + 1}/{n_bits}: {info.iterations} RLGC iterations ({info.stop_reason})")
 
-    def step(profile: bool) -> None:
-        deconvolve_bits(profile)
+    def decode() -> None:
         decoder.decode_one_tile(tile_idx=0, gpu_id=gpu_index, normalization_method="global")
         stats["transcripts"] = len(decoder.decoded_barcodes)
         stats["table"] = decoder.decoded_barcodes[["tile_z", "tile_y", "tile_x", "barcode_id"]]
         progress(f"decode_one_tile: {stats['transcripts']} transcripts")
+
+    def step(profile: bool) -> None:
+        if strong:
+            register_rounds(profile)
+        deconvolve_bits(profile)
+        decode()
 
     def fix_normalization() -> None:
         """Per-dataset analysis parameters, set once before timing: background = median and
@@ -346,55 +530,70 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # untimed: first pass deconvolves so the per-dataset global normalisation vectors exist
-    for w in range(max(args.warmup, 1)):
-        if w == 0:
-            deconvolve_bits(False)
-            fix_normalization()
-            decoder.decode_one_tile(tile_idx=0, gpu_id=gpu_index, normalization_method="global")
-        else:
-            step(False)
-    stats.update({"iters": 0, "conv_ms": 0.0, "conv_calls": 0, "transcripts": 0, "kernel_ms": [0.0] * 5,
-                  "loop_ms": 0.0})
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync()
-    elapsed = time.perf_counter() - t0
-    elapsed, total_iters = aggregate_over_ranks(elapsed, stats["iters"], world, device)
+    def decode_kernel_leg() -> dict:
+        """The one dense contraction of the path, outside the timed region: the fused decode kernel (exact-f32
+        MFMA distance step) on this tile's low-passed bit stack, HIP events on the stream it is launched on."""
+        decoder._tile_idx = 0
+        decoder._load_global_normalization_vectors(gpu_id=gpu_index)
+        decoder._load_bit_data(gpu_id=gpu_index)
+        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=gpu_index)
+        decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=gpu_index)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 3
+        ev[0].record()
+        for _ in range(reps):
+            decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=gpu_index)
+        ev[1].record()
+        torch.cuda.synchronize(device)
+        dec_ms = ev[0].elapsed_time(ev[1]) / reps
+        decoder._cleanup()
+        flop = 2.0 * n_bits * len(bits_matrix) * n_tile
+        return {
+            "kernel": "k_decode (scale, clip, L2 norm, codeword distances on v_mfma_f32_32x32x2_f32, argmin, thresholds)",
+            "bound": "mfma", "achieved": round(flop / (dec_ms * 1e-3) / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(flop / (dec_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "avg_ms": round(dec_ms, 3), "flop_per_launch": flop,
+            "hbm_gbs": round((4.0 * n_bits + 6.0 + 2.0 * n_bits) * n_tile / (dec_ms * 1e-3) / 1e9, 1),
+        }
 
-    if rank == 0:
-        n_tile = float(np.prod(shape))
-        value = world * args.steps * n_tile / elapsed / 1e6
-        pads = rl.pad_widths_zyx(shape, psf_shape)
-        padded = [s + a + b for s, (a, b) in zip(shape, pads)]
-        np_full = float(np.prod(padded))
+    extras: dict = {}
+
+    def record(steps_done: int, warm_done: int, elapsed: float, total_iters: float, tiles_done: int) -> dict:
+        value = tiles_done * n_tile / elapsed / 1e6
         conv_ms = stats["conv_ms"] / max(stats["conv_calls"], 1)
         conv_achieved = RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full / (conv_ms * 1e-3) / 1e9 if conv_ms else 0.0
         # one RLGC iteration = the launch unit of the dominant work: SURVEY.md section 8(d) prices it at
         # 148 B per padded voxel (4 convolutions x 20 B + 17 elementwise array passes x 4 B)
         iter_ms = stats["loop_ms"] / max(float(stats["iters"]), 1.0)  # this rank's loops / this rank's iterations
         achieved = RLGC_ALGORITHMIC_BYTES_PER_ITER_VOXEL * np_full / (iter_ms * 1e-3) / 1e9 if iter_ms else 0.0
+        what = (f"{n_bits} x RLGC (PSF {'x'.join(map(str, psf_shape))}, FFT volume {'x'.join(map(str, padded))}) + "
+                f"decode_one_tile")
+        if strong:
+            what = (f"{n_rounds} fiducial RLGC + {n_rounds - 1} x register_pair_to_fixed + " + what +
+                    " with per-round affine warps")
         out = {
             "metric": "Mvoxels/s through decon+decode, 22-bit codebook, 2048^2x64 tile",
             "value": round(value, 4),
             "unit": "Mvoxels/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "steps": steps_done,
+            "warmup": warm_done,
+            "steps_requested": args.steps,
+            "warmup_requested": args.warmup,
+            "wall_budget_s": budget,
+            "ms_per_step": round(elapsed / max(steps_done, 1) * 1e3, 2),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"configs[{1 if args.workload == 'config2' else 0}]: synthetic "
-                             f"{shape[0]}x{shape[1]}x{shape[2]} tile per GPU, {n_bits}-bit/{len(bits_matrix)}-codeword "
-                             f"codebook, {n_bits} x RLGC (PSF {'x'.join(map(str, psf_shape))}, FFT volume "
-                             f"{'x'.join(map(str, padded))}) + decode_one_tile"),
-                "tiles_per_step": world,
+                "workload": (f"configs[{CONFIG_INDEX[args.workload]}]: synthetic {shape[0]}x{shape[1]}x{shape[2]} "
+                             + (f"tiles, a {args.tiles}-tile volume dealt to {world} rank(s) in contiguous ranges, "
+                                if strong else "tile per GPU, ")
+                             + f"{n_bits}-bit/{len(bits_matrix)}-codeword codebook, per tile {what}"),
+                "tiles_per_step": tiles_done // max(steps_done, 1),
+                "tiles_timed": tiles_done,
                 "emitters_per_tile": n_emitters,
             },
             "rlgc_iterations_total": total_iters,
@@ -443,50 +642,110 @@ def main() -> None:
                  "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
                  "bytes_per_voxel": round(bpv, 2)}
                 for nme, ms, bpv in zip(names, stats["kernel_ms"], moved)]
+        if strong and stats["reg_calls"]:
+            out["registration"] = {
+                "what": "register_pair_to_fixed per moving round (host wall time around the call, first-seen "
+                        "transform shapes included)",
+                "calls_rank0": stats["reg_calls"], "avg_s": round(stats["reg_s"] / stats["reg_calls"], 4),
+                "max_shift_error_px": round(stats["reg_err_px"], 4)}
         # sanity of the decoded table against the planted emitters (voxel units, 3-voxel radius, same
         # codeword, one-to-one): the scorer of the simulation pipeline, not a timed quantity
-        scoring = importlib.import_module("merfish3d-analysis_amd.scoring")
         table = stats.get("table")
-        if table is not None:
+        if table is not None and len(table):
+            truth = current["truth"]
             f1 = scoring.calculate_F1_with_radius(
                 table[["tile_z", "tile_y", "tile_x"]].to_numpy(dtype=float), table["barcode_id"].to_numpy() - 1,
                 truth[:, 1:4].astype(float), truth[:, 0], 3.0)[0]
             out["f1_vs_planted_emitters"] = {k: (round(v, 4) if isinstance(v, float) else int(v)) for k, v in f1.items()}
-        # the one dense contraction of the path, outside the timed region: the fused decode kernel
-        # (exact-f32 MFMA distance step) on this tile's low-passed bit stack, HIP events on the
-        # stream it is launched on
-        decoder._tile_idx = 0
-        decoder._load_global_normalization_vectors(gpu_id=gpu_index)
-        decoder._load_bit_data(gpu_id=gpu_index)
-        decoder._lp_filter(sigma=PD.DEFAULT_DECODE_LOWPASS_SIGMA, gpu_id=gpu_index)
-        decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=gpu_index)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        reps = 3
-        ev[0].record()
-        for _ in range(reps):
-            decoder._decode_pixels(magnitude_threshold=PD.DEFAULT_DECODE_MAGNITUDE_THRESHOLD, gpu_id=gpu_index)
-        ev[1].record()
-        torch.cuda.synchronize(device)
-        dec_ms = ev[0].elapsed_time(ev[1]) / reps
-        decoder._cleanup()
-        flop = 2.0 * n_bits * len(bits_matrix) * n_tile
-        out["roofline_decode"] = {
-            "kernel": "k_decode (scale, clip, L2 norm, codeword distances on v_mfma_f32_32x32x2_f32, argmin, thresholds)",
-            "bound": "mfma", "achieved": round(flop / (dec_ms * 1e-3) / 1e12, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(flop / (dec_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
-            "avg_ms": round(dec_ms, 3), "flop_per_launch": flop,
-            "hbm_gbs": round((4.0 * n_bits + 6.0 + 2.0 * n_bits) * n_tile / (dec_ms * 1e-3) / 1e9, 1),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            iters_per_bit = total_iters / max(args.steps * n_bits, 1)
-            out["cpu_baseline"] = cpu_baseline(readouts[0], psf, bits_matrix, shape, n_bits, iters_per_bit)
-            out["io"] = io_leg(readouts, predictors, n_bits, out["ms_per_step"] / 1e3, float(np.prod(shape)))
-        print(json.dumps(out), flush=True)
+        out.update(extras)
+        if "io" in out:
+            io = dict(out["io"])
+            step_s = elapsed / max(tiles_done, 1)
+            io["value_including_load"] = round(n_tile / (step_s + io["load_seconds_per_tile"]) / 1e6, 4)
+            out["io"] = io
+        return out
+
+    # ---- untimed: the first tile deconvolves so that the per-dataset global normalisation vectors exist, and
+    # ---- its duration sizes the rest of the run
+    my_tiles = list(contiguous_share(args.tiles, world, rank)) if strong else None
+    if strong and args.tiles < world:
+        raise SystemExit(f"config3 deals whole tiles: --tiles {args.tiles} < {world} ranks")
+    load_tile((100 + my_tiles[0]) if strong else (1 + rank))
+    progress("synthetic tile ready")
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    if strong:
+        register_rounds(False)
+    deconvolve_bits(False)
+    fix_normalization()
+    decode()
+    torch.cuda.synchronize(device)
+    first_tile_s = time.perf_counter() - t0
+    warm_iters_per_call = stats["iters"] / max(rlgc_calls_per_tile, 1)
+    warm_done = 1
+    progress(f"first (untimed) tile: {first_tile_s:.1f} s; {seconds_left():.0f} s of the {budget:.0f} s budget left")
+
+    if rank == 0 and world == 1:
+        extras["roofline_decode"] = decode_kernel_leg()
+        if not args.no_cpu_baseline:
+            extras["cpu_baseline"] = cpu_baseline(current["readouts"][0], psf, bits_matrix, shape, n_bits,
+                                                  warm_iters_per_call, rlgc_calls_per_tile)
+            progress(f"cpu_baseline: {extras['cpu_baseline']['value']:.5f} Mvoxels/s")
+            extras["io"] = io_leg(current["readouts"], current["predictors"], n_bits)
+            progress("io leg done")
+
+    if strong:
+        # a fixed volume: every rank walks its contiguous share once; a rank whose share does not fit the
+        # budget stops early and the record says how many tiles were timed
+        n_fit = steps_that_fit(len(my_tiles), first_tile_s + 0.25 * first_tile_s, seconds_left())
+        n_steps = agree_min(n_fit if n_fit < len(my_tiles) else 10 ** 6, world, device)
+        n_steps = min(n_steps, max(len(contiguous_share(args.tiles, world, r)) for r in range(world)))
+    else:
+        for _ in range(max(args.warmup - 1, 0)):   # further warm-up tiles only if they leave room for a timed one
+            if seconds_left() < 3.2 * first_tile_s:
+                break
+            step(False)
+            warm_done += 1
+        n_steps = agree_min(steps_that_fit(args.steps, first_tile_s, seconds_left()), world, device)
+    reset_stats()
+
+    elapsed_sum = 0.0
+    tiles_done_rank = 0
+    steps_done = 0
+    last = None
+    for i in range(n_steps):
+        if strong:
+            mine = i < len(my_tiles)
+            if mine and i > 0:
+                load_tile(100 + my_tiles[i])       # synthesis stays outside the timed region
+        else:
+            mine = True
+        sync()
+        t0 = time.perf_counter()
+        if mine:
+            step(True)
+            tiles_done_rank += 1
+        sync()
+        elapsed_sum += time.perf_counter() - t0
+        steps_done += 1
+        elapsed, total_iters = aggregate_over_ranks(elapsed_sum, stats["iters"], world, device)
+        tiles_all = aggregate_over_ranks(0.0, tiles_done_rank, world, device)[1]
+        if rank == 0:
+            last = record(steps_done, warm_done, elapsed, total_iters, int(tiles_all))
+            print(json.dumps(last), flush=True)
+        # the measured step time replaces the warm-up estimate; stop (on every rank) if the next step would
+        # overrun the budget
+        per_step = elapsed / steps_done
+        stop = agree_min(0 if seconds_left() < 1.1 * per_step else 1, world, device) == 0
+        if stop and i + 1 < n_steps:
+            progress(f"stopping after {steps_done} timed step(s): wall budget")
+            break
     if world > 1:
         import torch.distributed as dist
 
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
