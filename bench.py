@@ -701,8 +701,11 @@ def main() -> int:
         n_steps = agree_min(n_fit if n_fit < len(my_tiles) else 10 ** 6, world, device)
         n_steps = min(n_steps, max(len(contiguous_share(args.tiles, world, r)) for r in range(world)))
     else:
-        for _ in range(max(args.warmup - 1, 0)):   # further warm-up tiles only if they leave room for a timed one
-            if seconds_left() < 3.2 * first_tile_s:
+        # further warm-up tiles: at most one (the first tile already ran every kernel ~1600 times; the second
+        # one runs with the plan, OTF and normalisation vectors in their steady state), and only if it leaves
+        # room for timed tiles - the budget goes to the timed region
+        for _ in range(min(max(args.warmup - 1, 0), 1)):
+            if seconds_left() < 4.5 * first_tile_s:
                 break
             step(False)
             warm_done += 1
