@@ -1,0 +1,55 @@
+"""CPU: bench.py's host logic - wall-budget step count, tile shares of the strong-scaling workload, and the
+plain ``--gpus N`` start (N ranks as a child process, loud failure when the node has fewer GPUs)."""
+
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def bench():
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        import bench as mod
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_steps_are_an_upper_bound_under_the_wall_budget(bench):
+    # the driver's command: 20 steps of ~37 s with ~400 s left -> what fits, never zero
+    assert bench.steps_that_fit(20, 36.5, 400.0) == 10
+    assert bench.steps_that_fit(20, 36.5, 10.0) == 1
+    assert bench.steps_that_fit(3, 1.0, 400.0) == 3
+    assert bench.steps_that_fit(4, 0.0, 5.0) == 4
+
+
+def test_contiguous_tile_shares_cover_the_volume(bench):
+    for tiles, world in ((64, 8), (8, 8), (10, 4), (7, 2), (8, 1)):
+        shares = [list(bench.contiguous_share(tiles, world, r)) for r in range(world)]
+        assert sum(shares, []) == list(range(tiles))
+        assert max(map(len, shares)) - min(map(len, shares)) <= 1
+
+
+def test_plain_multi_gpu_start_fails_loudly_without_the_gpus():
+    """WORLD_SIZE unset and --gpus 2 on a node with fewer GPUs: no silent one-GPU measurement."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("node has the GPUs")
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "only" in p.stderr and "GPU" in p.stderr
+    assert not any(line.startswith("{") for line in p.stdout.splitlines())
+
+
+def test_world_size_must_match_gpus():
+    env = dict(__import__("os").environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
