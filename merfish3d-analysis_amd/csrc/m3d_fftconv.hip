@@ -66,6 +66,8 @@ struct FftConvPlan {
     int rset_x, rset_y, rset_z;  // 1: lean kernels (no radix 16 / 8 stage on that axis)
     int ythreads, zthreads, xthreads, gx, gy, gz, dual_rows, dual_threads, zmirror;
     int zreg;  // Zp / 16 when the register variant of the Z pass applies (Zp = 32, 64, 128, 256), else 0
+    int xreg;  // X passes with register edge stages (radix list 9 ... 9, Xp / 9 <= 254, 256 threads)
+    int lch;   // log2 of the rows per y chunk of the spectrum layout
 };
 
 }  // namespace m3d
@@ -77,6 +79,7 @@ struct ConvGeo {
     int lTW, lNB, lP;  // log2 of TW, RB/2, P (all powers of two)
     int GX, GY, GZ;    // transforms one thread carries through a butterfly of each pass
     int lDR;           // log2 of the rows one block of the dual X inverse pass handles
+    int lCH;           // log2 of the rows per y chunk of the spectrum layout (see spec_index)
     int64_t plane;
     m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
     m3d::ConvBox mir;      // mirror != 0: the input is the symmetric extension of this box
@@ -84,13 +87,40 @@ struct ConvGeo {
     int zmirror;           // the spectrum holds the box's z planes only; the Z pass mirrors them in LDS
 };
 
+// Layout of one z plane of the half spectrum (plane = nT * Yp * TW complex elements): rows are grouped in chunks of
+// CH = 2^lCH consecutive y; inside a chunk the kx tiles follow each other, each tile holding its rows x TW values:
+//     S[z][y / CH][kx / TW][y % CH][kx % TW]          (the last chunk has Yp % CH rows)
+// A Y pass reads its column tile as Yp / CH runs of CH * TW * 8 bytes (4 KB at CH = 128, TW = 4); an X pass block (four
+// rows, all kx) touches 128-byte lines that are 4 KB apart, and the blocks of neighbouring rows - which run at the same
+// time - fill the lines in between.  With CH >= Yp this is the plain tiled layout S[z][kx / TW][y][kx % TW], whose
+// lines of one X block lie 70 KB apart: measured 2.3 TB/s for the X forward pass's stores against 3.5 TB/s chunked
+// (profiles/r02_x_forward_variants.txt) - DRAM page locality, not line completeness, is what the stores pay for.
+// row_base: in-plane offset of (y, kx = 0) and the row count of y's chunk.
+__device__ __forceinline__ int row_base(const ConvGeo &g, int y, int &rows_c)
+{
+    const int y0c = (y >> g.lCH) << g.lCH;
+    rows_c = min(1 << g.lCH, g.Yp - y0c);
+    return (y0c * g.nT + (y - y0c)) << g.lTW;
+}
+__device__ __forceinline__ int tile_term(const ConvGeo &g, int k, int rows_c)
+{
+    return (((k >> g.lTW) * rows_c) << g.lTW) + (k & (g.TW - 1));
+}
 // z is uniform per block in every caller: keeping its term apart leaves one 64-bit product per block and 32-bit
 // arithmetic per element (nT * Yp * TW < 2^31 is checked when the plan is made)
 __device__ __forceinline__ int64_t spec_index(const ConvGeo &g, int z, int y, int k)
 {
     const int64_t zterm = (int64_t)z * g.plane;  // plane = nT * Yp * TW
-    const int in_plane = (((k >> g.lTW) * g.Yp + y) << g.lTW) + (k & (g.TW - 1));
-    return zterm + in_plane;
+    int rows_c;
+    const int rb = row_base(g, y, rows_c);
+    return zterm + rb + tile_term(g, k, rows_c);
+}
+// element e = y * TW + kk of column tile kt (the order a Y pass keeps it in LDS) -> in-plane offset
+__device__ __forceinline__ int tile_elem(const ConvGeo &g, int kt, int e)
+{
+    int rows_c;
+    const int rb = row_base(g, e >> g.lTW, rows_c);
+    return rb + ((kt * rows_c) << g.lTW) + (e & (g.TW - 1));
 }
 
 // One tile per block; several blocks share a CU (LDS 16-70 KB each) so the load / transform /
@@ -435,6 +465,519 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(float2 *__restrict__ spe
     }
 }
 
+// In-kernel phase stamps (diagnostic builds only: -DM3D_STAMPS; scripts/gpu_stamps.py reads them back).
+#ifdef M3D_STAMPS
+__device__ unsigned long long m3d_stamp_buf[512 * 16];
+#define M3D_STAMP_DECL unsigned long long ts_[16]; for (int i_ = 0; i_ < 16; ++i_) ts_[i_] = 0; \
+    const bool stamp_on_ = threadIdx.x == M3D_STAMP_TID && blockIdx.x >= 8192 && blockIdx.x < 8192 + 512;
+#define M3D_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (stamp_on_) ts_[i] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#define M3D_STAMP_FLUSH do { if (stamp_on_) { ts_[15] = __builtin_amdgcn_s_memrealtime(); \
+    for (int i_ = 0; i_ < 16; ++i_) m3d_stamp_buf[(blockIdx.x - 8192) * 16 + i_] = ts_[i_]; } } while (0)
+#ifndef M3D_STAMP_TID
+#define M3D_STAMP_TID 0
+#endif
+#else
+#define M3D_STAMP_DECL
+#define M3D_STAMP(i) do { } while (0)
+#define M3D_STAMP_FLUSH do { } while (0)
+#endif
+
+// ================================================================ X passes with register edge stages
+// PMC passes over the kernels above (profiles/r02_pmc_sq_rlgc_before.json): waves parked on s_waitcnt / barriers half
+// of their lifetime, 30 % of the LDS cycles lost to bank conflicts, and the gather / split phases - chains of dependent
+// `pos` table loads around scattered LDS accesses - cost as much as the four transform stages between them.  For lengths
+// N = 9 S whose radix list starts and ends with 9 (2187 = 9 * 9 * 3 * 9, 324 = 9 * 4 * 9) and S <= 256 the two outer
+// stages run in registers instead:
+//   * the stage of block size N touches x[t + S q], q < 9 - the elements thread t loads from / stores to a real row
+//     with coalesced 4-byte accesses (forward: rows -> registers -> butterfly -> LDS; inverse: LDS -> butterfly ->
+//     registers -> fused tail -> rows): no LDS round trip, no barrier on that side, every global load issued up front;
+//   * the stage of block size 9 works on 9 adjacent LDS positions = the frequencies k' + S d, d < 9.  N - (k' + S d)
+//     = (S - k') + S (8 - d), so the blocks of k' and S - k' hold each other's mirror frequencies: one thread owns both
+//     and does the Hermitian split / merge in registers, writing or reading the tiled spectrum directly.  The digit-
+//     reversed position of a block is pos[k'] / 9 - two table loads per thread instead of two per element.
+// LDS passes per transform: 1 write + (stages - 2) read-modify-writes + 1 read (2187: 3 + 3 instead of 5 + 5), three
+// barriers instead of five.
+__device__ __forceinline__ void edge_twiddles(float2 (&w)[9], const float2 *__restrict__ tw, int t)
+{
+    // W_N^(t q), q < 9: powers 1, 2, 4 from the table (8 t < N), the rest by products - as lds_stage<9>
+    w[1] = tw[t];
+    w[2] = tw[2 * t];
+    w[4] = tw[4 * t];
+    w[3] = cmul(w[1], w[2]);
+    w[5] = cmul(w[1], w[4]);
+    w[6] = cmul(w[2], w[4]);
+    w[7] = cmul(w[3], w[4]);
+    w[8] = cmul(w[4], w[4]);
+}
+
+// middle stages of the DIF forward transform (block sizes S ... 9 exclusive of the two register stages)
+template <int RSET>
+__device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, int nb, int N, int tid, int nt, int gmax)
+{
+    int M = N / 9;
+    for (int s = 1; s < ax.nstages - 1; ++s) {
+        const int r = ax.radix[s];
+        lds_stage_r<false, RSET>(r, lds, N, M, 1, nb, N, ax.tw, tid, nt, gmax);
+        M /= r;
+        __syncthreads();
+    }
+}
+template <int RSET>
+__device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, int nb, int N, int tid, int nt, int gmax)
+{
+    int M = 9;
+    for (int s = ax.nstages - 2; s >= 1; --s) {
+        const int r = ax.radix[s];
+        M *= r;
+        lds_stage_r<true, RSET>(r, lds, N, M, 1, nb, N, ax.tw, tid, nt, gmax);
+        __syncthreads();
+    }
+}
+
+// Last forward stage + Hermitian split for the pair of 9-blocks (k', S - k') of the packed transform at `row`
+// (LDS): A (first packed real row) -> dstA[k], B -> dstB[k] for the nine frequencies k < Xc of the pair.
+// `sa` / `sb`: element offsets of k = 0 in the tiled spectrum rows (only the tile term depends on k).
+// LDS staging of one block's output lines (TW = 4, four rows per block: tile kt of rows y0 .. y0 + 3 is one 128-byte
+// line = eight 16-byte chunks, chunk c = 2 r + kk / 2).  Chunks are XOR-swizzled by the line index so that the split's
+// 8-byte writes (lanes = consecutive k) and the 16-byte read-back (lanes = consecutive chunks) are both conflict free.
+__device__ __forceinline__ int stage_slot(int k, int r)
+{
+    const int L = k >> 2, kk = k & 3, c = 2 * r + (kk >> 1);
+    return ((L * 8 + (c ^ (L & 7))) << 1) + (kk & 1);
+}
+
+// Last forward stage for the pair of 9-blocks (k', S - k'): both blocks read from LDS and transformed in registers.
+__device__ __forceinline__ void forward_pair_load(const float2 *row, int u1, int u2, float2 (&c1)[9], float2 (&c2)[9])
+{
+#pragma unroll
+    for (int q = 0; q < 9; ++q) c1[q] = row[9 * u1 + q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) c2[q] = row[9 * u2 + q];
+#ifndef M3D_XF_COPYONLY
+    dft9<false>(c1);
+    dft9<false>(c2);
+#endif
+}
+
+// Hermitian split of the pair: A (first packed real row) and B for the nine frequencies k < Xc of the pair, written
+// to the tiled spectrum rows ya / ya + 1 directly, or (STAGED) into the block's line staging at rows r0 / r0 + 1.
+template <bool STAGED = false>
+__device__ __forceinline__ void forward_pair_emit(const float2 (&c1)[9], const float2 (&c2)[9], const ConvGeo &g, int S,
+                                                  int kp, float2 *__restrict__ spec, int64_t zterm, int ya, bool wa,
+                                                  bool wb, float2 *stage = nullptr, int r0 = 0)
+{
+    const int k2p = kp == 0 ? 0 : S - kp;
+    int rows_c = 0;
+    const int rbase = STAGED ? 0 : row_base(g, min(ya, g.Yp - 1), rows_c);
+    auto put = [&](int k, float2 c, float2 m) {
+#ifdef M3D_XF_NOSTORE
+        if (c.x != 1.2345e30f) return;
+#endif
+        if constexpr (STAGED) {
+            stage[stage_slot(k, r0)] = make_float2(0.5f * (c.x + m.x), 0.5f * (c.y - m.y));
+            stage[stage_slot(k, r0 + 1)] = make_float2(0.5f * (c.y + m.y), 0.5f * (m.x - c.x));
+        } else {
+            const int in_plane = rbase + tile_term(g, k, rows_c);  // row ya + 1 (same chunk: ya is even) follows at + TW
+            if (wa) spec[zterm + in_plane] = make_float2(0.5f * (c.x + m.x), 0.5f * (c.y - m.y));
+            if (wb) spec[zterm + in_plane + g.TW] = make_float2(0.5f * (c.y + m.y), 0.5f * (m.x - c.x));
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < 5; ++d) put(kp + S * d, c1[d], kp == 0 ? c1[(9 - d) % 9] : c2[8 - d]);
+    if (k2p != kp) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) put(k2p + S * d, c2[d], c1[8 - d]);
+    }
+}
+
+// Write-out of a block's staged lines: one 16-byte chunk per lane, eight lanes per 128-byte line - every store
+// instruction writes whole lines (the direct form writes a quarter of sixteen lines per instruction and runs at
+// 2.3 TB/s; profiles/r02_x_forward_variants.txt).  rows_ok: bit r set = row y0 + r is inside the box.
+__device__ __forceinline__ void store_staged_lines(const float2 *stage, const ConvGeo &g, float2 *__restrict__ spec,
+                                                   int64_t zterm, int y0, unsigned rows_ok, int tid, int nt)
+{
+    const float4 *st4 = (const float4 *)stage;
+    int rows_c;
+    const int rbase = row_base(g, y0, rows_c);  // y0 .. y0 + 3 share a chunk (y0 and the chunk size are multiples of 4)
+    for (int i = tid; i < g.nT * 8; i += nt) {
+        const int L = i >> 3, c = (i & 7) ^ (L & 7), r = c >> 1, k = 4 * L + 2 * (c & 1);
+        if (!((rows_ok >> r) & 1u) || k >= g.Xc) continue;
+        const float4 v = st4[i];
+        float2 *dst = spec + zterm + rbase + ((L * rows_c + r) << 2) + 2 * (c & 1);
+        if (k + 1 < g.Xc)
+            *(float4 *)dst = v;
+        else
+            *dst = make_float2(v.x, v.y);
+    }
+}
+
+// Hermitian merge + first inverse stage for the pair (k', S - k'): C = A + i B at the nine frequencies k < Xc of the
+// pair and conj(A) + i conj(B) at their mirrors, 9-point inverse butterflies, both blocks written to LDS.
+__device__ __forceinline__ void inverse_pair_merge(float2 *row, int S, int N, int kp, int u1, int u2,
+                                                   const float2 (&Av)[9], const float2 (&Bv)[9])
+{
+    // Av / Bv: [0..4] = block k' at d = 0..4, [5..8] = block S - k' at d = 0..3
+    float2 c1[9], c2[9];
+    const int k2p = kp == 0 ? 0 : S - kp;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        const float2 A = Av[d], B = Bv[d];
+        const int k = kp + S * d;
+        c1[d] = make_float2(A.x - B.y, A.y + B.x);
+        const float2 mir = make_float2(A.x + B.y, B.x - A.y);
+        if (kp == 0) {
+            if (d != 0) c1[9 - d] = mir;
+        } else if (2 * k != N) {
+            c2[8 - d] = mir;
+        }
+    }
+    if (k2p != kp) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const float2 A = Av[5 + d], B = Bv[5 + d];
+            c2[d] = make_float2(A.x - B.y, A.y + B.x);
+            c1[8 - d] = make_float2(A.x + B.y, B.x - A.y);
+        }
+        dft9<true>(c2);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) row[9 * u2 + q] = c2[q];
+    } else if (kp != 0) {  // k' = S / 2 (even S): the block mirrors onto itself, d <-> 8 - d
+#pragma unroll
+        for (int d = 0; d < 4; ++d) c1[8 - d] = c2[8 - d];
+    }
+    dft9<true>(c1);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) row[9 * u1 + q] = c1[q];
+}
+
+// spectrum element offsets of the pair's nine frequencies (row term excluded): [0..4] block k', [5..8] block S - k'
+__device__ __forceinline__ void pair_offsets(const ConvGeo &g, int S, int kp, int rows_c, int (&off)[9])
+{
+    const int k2p = kp == 0 ? 0 : S - kp;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) off[d] = tile_term(g, kp + S * d, rows_c);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) off[5 + d] = tile_term(g, k2p + S * d, rows_c);  // k2p == kp: loaded but unused
+}
+
+template <int RSET>
+__global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restrict__ src, float2 *__restrict__ spec,
+                                                      ConvGeo g, AxisPlan ax)
+{
+    extern __shared__ float2 lds_fr[];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int yg0 = (g.in.y0 / g.RB) * g.RB, y_hi = g.in.y0 + g.in.ny, x_hi = g.in.x0 + g.in.nx;
+    const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
+    const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
+    const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
+    M3D_STAMP_DECL
+    M3D_STAMP(0);
+    // the pair item of the last stage: its two block positions are requested now, used three barriers later
+    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    const bool pair_live = tid < nb * I;
+    int pu1 = 0, pu2 = 0;
+    if (pair_live) {
+        pu1 = ax.pos[kp];
+        pu2 = ax.pos[kp == 0 ? 0 : S - kp];
+    }
+    if (tid < S) {
+        float2 w[9];
+        edge_twiddles(w, ax.tw, tid);
+        const int zs = g.mirror == 1 ? sym_src(z, g.mir.z0, g.mir.nz) : z;
+        for (int bi = 0; bi < nb; ++bi) {
+            const int ya = y0 + 2 * bi, yb = ya + 1;
+            const bool va = ya >= g.in.y0 && ya < y_hi, vb = yb >= g.in.y0 && yb < y_hi;
+            const int yas = g.mirror == 1 ? sym_src(min(ya, g.Yp - 1), g.mir.y0, g.mir.ny) : (va ? ya : g.in.y0);
+            const int ybs = g.mirror == 1 ? sym_src(min(yb, g.Yp - 1), g.mir.y0, g.mir.ny) : (vb ? yb : g.in.y0);
+            const float *ra = src + ((int64_t)zs * g.Yp + yas) * N;
+            const float *rbp = src + ((int64_t)zs * g.Yp + ybs) * N;
+            float a[9], b[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                int n = tid + S * q;
+                if (g.mirror) n = sym_src(n, g.mir.x0, g.mir.nx);
+                else n = min(max(n, g.in.x0), x_hi - 1);
+#ifdef M3D_XF_NOLOAD
+                a[q] = (float)n * 1e-3f;
+                b[q] = (float)(n + ya) * 1e-3f;
+#else
+                a[q] = ra[n];
+                b[q] = rbp[n];
+#endif
+            }
+            float2 v[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int n = tid + S * q;
+                const bool vx = g.mirror || (n >= g.in.x0 && n < x_hi);
+                v[q] = make_float2(va && vx ? a[q] : 0.0f, vb && vx ? b[q] : 0.0f);
+            }
+            M3D_STAMP(1 + 2 * bi);   // loads of this row pair have landed
+#ifndef M3D_XF_COPYONLY
+            dft9<false>(v);
+#endif
+            float2 *row = lds_fr + bi * N + tid;
+            row[0] = v[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) row[S * q] = cmul(v[q], w[q]);
+            M3D_STAMP(2 + 2 * bi);   // first stage done
+        }
+    }
+    __syncthreads();
+    M3D_STAMP(5);
+#if !defined(M3D_XF_NOMID) && !defined(M3D_XF_COPYONLY)
+    middle_forward<RSET>(lds_fr, ax, nb, N, tid, nt, g.GX);
+#endif
+    M3D_STAMP(6);
+    {
+        float2 c1[9], c2[9];
+        if (pair_live) forward_pair_load(lds_fr + pbi * N, pu1 / 9, pu2 / 9, c1, c2);
+        const int ya = y0 + 2 * pbi;
+        const int64_t zterm = (int64_t)z * g.plane;
+        if (g.TW == 4 && g.RB == 4) {
+            __syncthreads();  // every pair has read its blocks: the buffer becomes the line staging
+            if (pair_live) forward_pair_emit<true>(c1, c2, g, S, kp, spec, zterm, ya, true, true, lds_fr, 2 * pbi);
+            __syncthreads();
+            unsigned rows_ok = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (y0 + r >= g.in.y0 && y0 + r < y_hi) rows_ok |= 1u << r;
+            store_staged_lines(lds_fr, g, spec, zterm, y0, rows_ok, tid, nt);
+        } else if (pair_live) {
+            forward_pair_emit<false>(c1, c2, g, S, kp, spec, zterm, ya, ya >= g.in.y0 && ya < y_hi,
+                                     ya + 1 >= g.in.y0 && ya + 1 < y_hi);
+        }
+    }
+    M3D_STAMP(7);
+#ifdef M3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    M3D_STAMP(8);
+    M3D_STAMP_FLUSH;
+}
+
+// Fused tails run on the registers of the last inverse stage: thread t holds x[t + S q] of both packed rows.
+template <int RSET, int EPI>
+__global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restrict__ spec, float *__restrict__ dst,
+                                                      ConvGeo g, AxisPlan ax, m3d::ConvEpilogue ep)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float2 lds_ir[];
+    __shared__ float smf[4];
+    __shared__ unsigned long long smu[4];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int yg0 = (g.out.y0 / g.RB) * g.RB, y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
+    const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
+    const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
+    const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
+    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    if (tid < nb * I) {
+        const int u1 = ax.pos[kp], u2 = ax.pos[kp == 0 ? 0 : S - kp];
+        const int ya = y0 + 2 * pbi;  // rows outside the box were not produced by the Y pass
+        const bool va = ya >= g.out.y0 && ya < y_hi, vb = ya + 1 >= g.out.y0 && ya + 1 < y_hi;
+        // an invalid row is read from its valid partner (and zeroed below), so both rows lie in one chunk
+        const int yac = va ? ya : (vb ? ya + 1 : g.out.y0), ybc = vb ? ya + 1 : yac;
+        int rows_c, off[9];
+        const int rba = row_base(g, yac, rows_c), rbb = rba + ((ybc - yac) << g.lTW);
+        pair_offsets(g, S, kp, rows_c, off);
+        const float2 *sa = spec + (int64_t)z * g.plane + rba;
+        const float2 *sb = spec + (int64_t)z * g.plane + rbb;
+        float2 Av[9], Bv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            Av[i] = sa[off[i]];
+            Bv[i] = sb[off[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (!va) Av[i] = make_float2(0.f, 0.f);
+            if (!vb) Bv[i] = make_float2(0.f, 0.f);
+        }
+        inverse_pair_merge(lds_ir + pbi * N, S, N, kp, u1 / 9, u2 / 9, Av, Bv);
+    }
+    __syncthreads();
+    middle_inverse<RSET>(lds_ir, ax, nb, N, tid, nt, g.GX);
+    float mx = -INFINITY, dmax = 0.0f;
+    unsigned long long updated = 0;
+    if (tid < S) {
+        float2 w[9];
+        edge_twiddles(w, ax.tw, tid);
+        for (int bi = 0; bi < nb; ++bi) {
+            const int yr[2] = {y0 + 2 * bi, y0 + 2 * bi + 1};
+            bool valid[2];
+            int64_t rowo[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                valid[r] = yr[r] >= g.out.y0 && yr[r] < y_hi;
+                rowo[r] = ((int64_t)z * g.Yp + (valid[r] ? yr[r] : g.out.y0)) * N;
+            }
+            float av[2][9], bv[2][9];
+            if constexpr (EPI != m3d::ConvEpilogue::kNone) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        av[r][q] = ep.a[rowo[r] + n];
+                        bv[r][q] = ep.b[rowo[r] + n];
+                    }
+                }
+            }
+            float2 v[9];
+            const float2 *row = lds_ir + bi * N + tid;
+            v[0] = row[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
+            dft9<true>(v);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int n = tid + S * q;
+                if (n < g.out.x0 || n >= x_hi) continue;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (!valid[r]) continue;
+                    const float c = r ? v[q].y : v[q].x;
+                    if constexpr (EPI == m3d::ConvEpilogue::kNone) {
+                        dst[rowo[r] + n] = c;
+                    } else if constexpr (EPI == m3d::ConvEpilogue::kUpdate) {
+                        const float old = av[r][q];
+                        const float nw = c < 0.0f ? old : old * bv[r][q];
+                        ep.o1[rowo[r] + n] = nw;
+                        updated += (c >= 0.0f) ? 1ull : 0ull;
+                        mx = fmaxf(mx, nw);
+                        dmax = fmaxf(dmax, fabsf(nw - old));
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (EPI == m3d::ConvEpilogue::kUpdate) {
+        updated = block_sum(updated, smu);
+        mx = block_max(mx, smf);
+        dmax = block_max(dmax, smf);
+        if (tid == 0) {
+            if (updated) atomicAdd((unsigned long long *)ep.red, updated);
+            atomicMax(&ep.red[2], m3d::float_key(mx));
+            atomicMax(&ep.red[3], __float_as_uint(dmax));
+        }
+    }
+}
+
+// Dual X inverse pass (two spectra -> HTratio1, HTratio2 of two rows) with the consensus arithmetic in registers and,
+// CHAIN, the product's X forward transform started from the same registers: the element the last inverse stage hands
+// thread t at x = t + S q is the element the first forward stage takes from it.
+template <int RSET, bool CHAIN>
+__global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
+                                                           const float2 *__restrict__ spec2, ConvGeo g, AxisPlan ax,
+                                                           m3d::ConvEpilogue ep)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float2 lds_dr[];
+    __shared__ float smf[4];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int N = g.Xp, S = N / 9, I = S / 2 + 1;
+    const int groups = (g.Yp + 1) / 2;
+    const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * 2;
+    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    const bool pair_live = tid < 2 * I;
+    int pu1 = 0, pu2 = 0;
+    if (pair_live) {
+        pu1 = ax.pos[kp] / 9;
+        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / 9;
+        int rows_c, off[9];
+        const int rb = row_base(g, min(y0 + pbi, g.Yp - 1), rows_c);
+        pair_offsets(g, S, kp, rows_c, off);
+        const int64_t rbase = (int64_t)z * g.plane + rb;
+        float2 Av[9], Bv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            Av[i] = spec1[rbase + off[i]];
+            Bv[i] = spec2[rbase + off[i]];
+        }
+        inverse_pair_merge(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
+    }
+    // update_norm of both rows: requested before the middle stages, used after them
+    const bool row1 = y0 + 1 < g.Yp;
+    const int64_t r0 = ((int64_t)z * g.Yp + y0) * N, r1 = r0 + (row1 ? N : 0);
+    float un0[9], un1[9];
+    if (tid < S) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            un0[q] = ep.b[r0 + tid + S * q];
+            un1[q] = ep.b[r1 + tid + S * q];
+        }
+    }
+    __syncthreads();
+    middle_inverse<RSET>(lds_dr, ax, 2, N, tid, nt, g.GX);
+    float mn = INFINITY, mx = -INFINITY;
+    if (tid < S) {
+        float2 w[9];
+        edge_twiddles(w, ax.tw, tid);
+        float2 v0[9], v1[9];
+        const float2 *row = lds_dr + tid;
+        v0[0] = row[0];
+        v1[0] = row[N];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) {
+            v0[q] = cmul_conj(row[S * q], w[q]);
+            v1[q] = cmul_conj(row[N + S * q], w[q]);
+        }
+        dft9<true>(v0);
+        dft9<true>(v1);
+        const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
+        const bool c0 = z_core && y0 >= ep.core.y0 && y0 < ep.core.y0 + ep.core.ny;
+        const bool c1 = z_core && row1 && y0 + 1 >= ep.core.y0 && y0 + 1 < ep.core.y0 + ep.core.ny;
+        float2 pk[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int n = tid + S * q;
+            const bool xc = n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx;
+            float prod[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float2 v = r ? v1[q] : v0[q];  // (HTratio1 raw, HTratio2 raw)
+                const float un = r ? un1[q] : un0[q];
+                const float h1 = v.x / un, h2 = v.y / un;
+                prod[r] = (h1 - 1.0f) * (h2 - 1.0f);
+                if (r == 0 || row1) {
+                    const float hs = h1 + h2;
+                    mn = fminf(mn, hs);
+                    mx = fmaxf(mx, hs);
+                    if ((r ? c1 : c0) && xc) ep.o2[(r ? r1 : r0) + n] = hs;
+                    if constexpr (!CHAIN) ep.o1[(r ? r1 : r0) + n] = prod[r];
+                }
+            }
+            pk[q] = make_float2(prod[0], row1 ? prod[1] : 0.0f);
+        }
+        if constexpr (CHAIN) {
+            // first forward stage of the packed product rows, from the registers that just produced them; the LDS
+            // slots written are the ones this thread read above
+#pragma clang fp contract(fast)
+            dft9<false>(pk);
+            float2 *orow = lds_dr + tid;
+            orow[0] = pk[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
+        }
+    }
+    mn = block_min(mn, smf);
+    mx = block_max(mx, smf);
+    if (tid == 0) {
+        atomicMin(&ep.red[0], m3d::float_key(mn));
+        atomicMax(&ep.red[1], m3d::float_key(mx));
+    }
+    if constexpr (CHAIN) {
+        __syncthreads();
+        middle_forward<RSET>(lds_dr, ax, 1, N, tid, nt, g.GX);
+        if (tid < I) {
+            float2 c1[9], c2[9];
+            forward_pair_load(lds_dr, pu1, pu2, c1, c2);
+            forward_pair_emit<false>(c1, c2, g, S, kp, spec1, (int64_t)z * g.plane, y0, true, row1);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- Y pass (in place)
 template <bool INV, int RSET>
 __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, ConvGeo g, AxisPlan ay)
@@ -445,17 +988,18 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
     // inverse: only the output's z planes are transformed and only its y rows are stored
     const m3d::ConvBox &bx = INV ? g.out : g.in;
     const int z = bx.z0 + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
-    float2 *tile = spec + ((int64_t)z * g.nT + kt) * g.Yp * g.TW;  // (z, kt) tiles are consecutive
+    float2 *pl = spec + (int64_t)z * g.plane;  // the tile's rows come in runs of one y chunk (tile_elem)
     const int n = g.Yp * g.TW;
     const int lo = INV ? 0 : bx.y0 * g.TW, hi = INV ? n : (bx.y0 + bx.ny) * g.TW;  // load range
     const int slo = INV ? bx.y0 * g.TW : 0, shi = INV ? (bx.y0 + bx.ny) * g.TW : n;  // store range
-    if ((g.TW & 1) == 0) {  // 16-byte copies (tile bases are 16-B aligned when TW is even)
-        float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
+    if ((g.TW & 1) == 0) {  // 16-byte copies (rows are 16-B aligned when TW is even)
+        float4 *l4 = (float4 *)lds_y;
         constexpr int kU = M3D_KU_Y;  // independent 16-byte loads in flight per thread (see k_z_conv)
         for (int i0 = tid; i0 < n / 2; i0 += nt * kU) {
             float4 v[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) v[u] = t4[min(max(i0 + u * nt, lo / 2), hi / 2 - 1)];
+            for (int u = 0; u < kU; ++u)
+                v[u] = *(const float4 *)(pl + tile_elem(g, kt, 2 * min(max(i0 + u * nt, lo / 2), hi / 2 - 1)));
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const int i = i0 + u * nt;
@@ -463,15 +1007,16 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
             }
         }
     } else {
-        for (int i = tid; i < n; i += nt) lds_y[i] = (i >= lo && i < hi) ? tile[i] : make_float2(0.f, 0.f);
+        for (int i = tid; i < n; i += nt)
+            lds_y[i] = (i >= lo && i < hi) ? pl[tile_elem(g, kt, i)] : make_float2(0.f, 0.f);
     }
     __syncthreads();
     lds_fft<INV, RSET>(lds_y, ay, g.TW, g.TW, 1, tid, nt, g.GY);
     if ((g.TW & 1) == 0) {
-        float4 *t4 = (float4 *)tile, *l4 = (float4 *)lds_y;
-        for (int i = slo / 2 + tid; i < shi / 2; i += nt) t4[i] = l4[i];
+        float4 *l4 = (float4 *)lds_y;
+        for (int i = slo / 2 + tid; i < shi / 2; i += nt) *(float4 *)(pl + tile_elem(g, kt, 2 * i)) = l4[i];
     } else {
-        for (int i = slo + tid; i < shi; i += nt) tile[i] = lds_y[i];
+        for (int i = slo + tid; i < shi; i += nt) pl[tile_elem(g, kt, i)] = lds_y[i];
     }
 }
 
@@ -487,18 +1032,17 @@ __global__ __launch_bounds__(1024) void k_y_forward_mirror(const float2 *__restr
     // zmirror: only the core planes are built (the Z pass reflects them); else every plane from its source
     const int z = (g.zmirror ? g.mir.z0 : 0) + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
     const int zs = sym_src(z, g.mir.z0, g.mir.nz);
-    const float2 *stile = src + ((int64_t)zs * g.nT + kt) * g.Yp * g.TW;
-    float2 *dtile = dst + ((int64_t)z * g.nT + kt) * g.Yp * g.TW;
+    const float2 *spl = src + (int64_t)zs * g.plane;
+    float2 *dpl = dst + (int64_t)z * g.plane;
     const int n = g.Yp * g.TW;
     const int lo = g.mir.y0 * g.TW, hi = (g.mir.y0 + g.mir.ny) * g.TW;
     {   // TW is even on this path: 16-byte copies
-        const float4 *t4 = (const float4 *)stile;
         float4 *l4 = (float4 *)lds_ym;
         constexpr int kU = M3D_KU_Y;
         for (int i0 = lo / 2 + tid; i0 < hi / 2; i0 += nt * kU) {
             float4 v[kU];
 #pragma unroll
-            for (int u = 0; u < kU; ++u) v[u] = t4[min(i0 + u * nt, hi / 2 - 1)];
+            for (int u = 0; u < kU; ++u) v[u] = *(const float4 *)(spl + tile_elem(g, kt, 2 * min(i0 + u * nt, hi / 2 - 1)));
 #pragma unroll
             for (int u = 0; u < kU; ++u)
                 if (i0 + u * nt < hi / 2) l4[i0 + u * nt] = v[u];
@@ -512,8 +1056,8 @@ __global__ __launch_bounds__(1024) void k_y_forward_mirror(const float2 *__restr
     }
     __syncthreads();
     lds_fft<false, RSET>(lds_ym, ay, g.TW, g.TW, 1, tid, nt, g.GY);
-    float4 *t4 = (float4 *)dtile, *l4 = (float4 *)lds_ym;
-    for (int i = tid; i < n / 2; i += nt) t4[i] = l4[i];
+    float4 *l4 = (float4 *)lds_ym;
+    for (int i = tid; i < n / 2; i += nt) *(float4 *)(dpl + tile_elem(g, kt, 2 * i)) = l4[i];
 }
 
 // ---------------------------------------------------------------- Z pass
@@ -735,7 +1279,7 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
 }
 
 
-bool factor_23(int n, int *radix, int *nstages, bool z_axis = false)
+bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis = false)
 {
     int c3 = 0, c2 = 0, m = n;
     while (m % 3 == 0) {
@@ -754,7 +1298,10 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false)
         c3 -= 3;
     }
 #endif
-    for (int i = 0; i < c3 / 2; ++i) radix[s++] = 9;
+    // X axis with two or more radix-9 stages: one of them goes last, so that both outer stages are radix 9 and can
+    // run in registers (k_x_forward_reg / k_x_inverse_reg)
+    const bool nine_last = x_axis && c3 >= 4 && getenv("M3D_FFT_XREG_ORDER") == nullptr;
+    for (int i = 0; i < c3 / 2 - (nine_last ? 1 : 0); ++i) radix[s++] = 9;
     if (c3 % 2) radix[s++] = 3;
     static const bool small_pow2 = getenv("M3D_FFT_BIG_RADIX") == nullptr;  // 4,4,4,2 beat 16,8 (VGPRs)
     // Z axis (short power-of-two transforms, k_z_conv<2>): as few radix-8 stages as bring the stage count
@@ -781,6 +1328,7 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false)
     }
     if (c2 == 2) radix[s++] = 4;
     if (c2 == 1) radix[s++] = 2;
+    if (nine_last) radix[s++] = 9;
     *nstages = s;
     return s <= kMaxStages;
 }
@@ -811,6 +1359,7 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
     g.GY = p->gy;
     g.GZ = p->gz;
     g.lDR = __builtin_ctz((unsigned)p->dual_rows);
+    g.lCH = p->lch;
     return g;
 }
 
@@ -826,7 +1375,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->Yp = Yp;
     p->Xp = Xp;
     p->Xc = Xp / 2 + 1;
-    if (!factor_23(Xp, p->ax.radix, &p->ax.nstages) || !factor_23(Yp, p->ay.radix, &p->ay.nstages) ||
+    if (!factor_23(Xp, p->ax.radix, &p->ax.nstages, false, true) || !factor_23(Yp, p->ay.radix, &p->ay.nstages) ||
         !factor_23(Zp, p->az.radix, &p->az.nstages, true)) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -857,6 +1406,8 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     // rows per X block: 4 real rows (2 packed) when they fit 40 KB, else 2
     p->RB = ((size_t)2 * Xp * sizeof(float2) <= 40 * 1024) ? knob("M3D_FFT_RB", 4) : 2;
     p->lds_x = (size_t)(p->RB / 2) * Xp * sizeof(float2);
+    // the X forward pass re-uses its buffer as a staging area of whole 128-byte spectrum lines (4 rows x TW = 4)
+    if (p->TW == 4 && p->RB == 4) p->lds_x = std::max(p->lds_x, (size_t)((Xp / 2 + 1 + 3) / 4) * 128);
     p->P = knob("M3D_FFT_P", 16);
     while (p->P > 1 && (size_t)Zp * p->P * sizeof(float2) > 64 * 1024) p->P /= 2;
     p->lds_z = (size_t)Zp * p->P * sizeof(float2);
@@ -869,7 +1420,16 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->dual_rows = knob("M3D_FFT_DUAL_ROWS", 2);
     p->dual_threads = knob("M3D_FFT_DUAL_T", 256);
     p->ythreads = knob("M3D_FFT_YT", 768);
+    {   // rows per y chunk of the spectrum layout: a power of two >= 4 (whole X blocks); >= Yp = plain tiled layout
+        int ch = std::max(4, knob("M3D_FFT_CH", 128));
+        p->lch = 31 - __builtin_clz((unsigned)ch);
+        if ((1 << p->lch) >= Yp) p->lch = 30;
+    }
     p->zthreads = std::max(p->P, knob("M3D_FFT_ZT", 128));
+    p->xreg = (knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 9 &&
+               p->ax.radix[p->ax.nstages - 1] == 9 && p->xthreads == 256 && p->dual_threads == 256 &&
+               p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 256 && Xp / 9 <= 256)
+                  ? 1 : 0;
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -999,6 +1559,21 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
 }
 
+static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spec, const ConvGeo &g, int groups,
+                             hipStream_t st)
+{
+    const dim3 grid((unsigned)(g.in.nz * groups)), block(p->xthreads);
+    if (p->xreg) {
+        if (p->rset_x)
+            hipLaunchKernelGGL(k_x_forward_reg<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
+        else
+            hipLaunchKernelGGL(k_x_forward_reg<0>, grid, block, p->lds_x, st, src, spec, g, p->ax);
+    } else if (p->rset_x)
+        hipLaunchKernelGGL(k_x_forward<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
+    else
+        hipLaunchKernelGGL(k_x_forward<0>, grid, block, p->lds_x, st, src, spec, g, p->ax);
+}
+
 static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
                              EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                              const ConvBox *mirror_box = nullptr, float2 *spec_alt = nullptr)
@@ -1012,10 +1587,7 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         const unsigned yplanes = (unsigned)(p->zmirror ? g.mir.nz : p->Zp);
         const int groups = row_groups(p, g.in);
         if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
-        if (p->rset_x)
-            hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
-        else
-            hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
+        launch_x_forward(p, src, spec, g, groups, st);
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
         if (p->rset_y)
             hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
@@ -1028,10 +1600,7 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
     const int groups = row_groups(p, g.in);
     if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
     if (src) {  // src == nullptr: the half-spectrum rows are already in `spec` (chained from another pass)
-        if (p->rset_x)
-            hipLaunchKernelGGL(k_x_forward<1>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
-        else
-            hipLaunchKernelGGL(k_x_forward<0>, dim3((unsigned)(g.in.nz * groups)), dim3(p->xthreads), p->lds_x, st, src, spec, g, p->ax);
+        launch_x_forward(p, src, spec, g, groups, st);
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
     }
     if (p->rset_y)
@@ -1098,7 +1667,18 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
     const int nb = p->dual_rows;
     const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
     const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
-    if (chain_forward) {
+    if (p->xreg) {
+#define M3D_LAUNCH_XD(RS, CH) \
+    hipLaunchKernelGGL((k_x_inverse_dual_reg<RS, CH>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue)
+        if (chain_forward) {
+            if (p->rset_x) M3D_LAUNCH_XD(1, true);
+            else M3D_LAUNCH_XD(0, true);
+        } else {
+            if (p->rset_x) M3D_LAUNCH_XD(1, false);
+            else M3D_LAUNCH_XD(0, false);
+        }
+#undef M3D_LAUNCH_XD
+    } else if (chain_forward) {
         if (p->rset_x)
             hipLaunchKernelGGL((k_x_inverse_dual<1, true>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
@@ -1129,6 +1709,17 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
         return M3D_ERR_INVALID_ARG;
 #define M3D_LAUNCH_XI(RS, EP) \
     hipLaunchKernelGGL((k_x_inverse<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
+#define M3D_LAUNCH_XIR(RS, EP) \
+    hipLaunchKernelGGL((k_x_inverse_reg<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
+    if (p->xreg && ep.kind != ConvEpilogue::kConsensus) {
+        if (p->rset_x) {
+            if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XIR(1, 2);
+            else M3D_LAUNCH_XIR(1, 0);
+        } else {
+            if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XIR(0, 2);
+            else M3D_LAUNCH_XIR(0, 0);
+        }
+    } else
     if (p->rset_x) {
         if (ep.kind == ConvEpilogue::kConsensus) M3D_LAUNCH_XI(1, 1);
         else if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XI(1, 2);
@@ -1139,9 +1730,17 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
         else M3D_LAUNCH_XI(0, 0);
     }
 #undef M3D_LAUNCH_XI
+#undef M3D_LAUNCH_XIR
     if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
 
 }  // namespace m3d
+
+#ifdef M3D_STAMPS
+extern "C" int m3d_debug_stamps(unsigned long long *host, int count)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(m3d_stamp_buf), sizeof(unsigned long long) * (size_t)count) == hipSuccess ? 0 : -3;
+}
+#endif
