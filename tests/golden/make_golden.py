@@ -309,6 +309,27 @@ def synth_bit_stack(codebook_df, n_bits, shape, n_spots, seed):
     return stack.astype(np.float32), np.asarray(truth, dtype=np.int64)
 
 
+def _record_f32(dec):
+    """Keep what ``_calculate_distances`` / ``_normalize_pixel_traces`` return per plane: the reference rounds to 5
+    decimals and stores float16 (PixelDecoder.py:2621-2632), the float32 values are what "distances within 1e-4"
+    is about."""
+    rec = {"distance": [], "magnitude": []}
+    calc, norm = dec._calculate_distances, dec._normalize_pixel_traces
+
+    def calc_rec(*a, **k):
+        d, i = calc(*a, **k)
+        rec["distance"].append(np.asarray(d, dtype=np.float32).copy())
+        return d, i
+
+    def norm_rec(*a, **k):
+        n, m = norm(*a, **k)
+        rec["magnitude"].append(np.asarray(m, dtype=np.float32).copy())
+        return n, m
+
+    dec._calculate_distances, dec._normalize_pixel_traces = calc_rec, norm_rec
+    return rec
+
+
 def make_decode(pdm):
     for name, n_bits, n_codes, shape, seed, excl in (
         ("decode_pixels_16", 16, 140, (6, 48, 52), 11, None),
@@ -330,9 +351,12 @@ def make_decode(pdm):
         dec._global_normalization_vector = nrm
         dec._global_normalization_loaded = True
         mag_thr = (0.9, 10.0)
+        f32 = _record_f32(dec)
         dec._decode_pixels(magnitude_threshold=mag_thr)
         np.savez_compressed(
             HERE / f"{name}.npz",
+            distance_f32=np.stack(f32["distance"]).reshape(dec._distance_image.shape),
+            magnitude_f32=np.stack(f32["magnitude"]).reshape(dec._magnitude_image.shape),
             codebook_bits=cb.iloc[:, 1 : n_bits + 1].to_numpy(dtype=np.int8),
             gene_ids=np.asarray(cb["gene_id"].tolist()),
             stack=stack,
@@ -360,9 +384,12 @@ def make_decode(pdm):
     dec._image_data = stack
     dec._lp_filter(sigma=(3.0, 1.0, 1.0))
     lp2 = dec._image_data_lp.copy()
+    f32 = _record_f32(dec)
     dec._decode_pixels(magnitude_threshold=(0.7, 10.0))
     np.savez_compressed(
         HERE / "decode_pixels_2d_none.npz",
+        distance_f32=np.stack(f32["distance"]).reshape(dec._distance_image.shape),
+        magnitude_f32=np.stack(f32["magnitude"]).reshape(dec._magnitude_image.shape),
         codebook_bits=cb.iloc[:, 1:17].to_numpy(dtype=np.int8),
         stack=stack,
         lowpass=lp2,
@@ -385,6 +412,116 @@ def make_decode(pdm):
         expected=pdm.PixelDecoder._warp_pixel(pixel, spacing, origin, ga, c2s),
         expected_no_camera=pdm.PixelDecoder._warp_pixel(pixel, spacing, origin, ga, None),
     )
+
+
+# ----------------------------------------------------------------------------
+# _extract_barcodes: the reference's own table assembly over pinned library arithmetic
+# ----------------------------------------------------------------------------
+def _skimage_standins():
+    """``label`` / ``remove_small_objects`` / ``regionprops_table`` with the scikit-image API the reference calls,
+    computed by ``oracle.ccl_ref`` - whose labels, areas, centroids, float16 ``intensity_mean``, eigenvalues and
+    ``intensity_min`` are themselves pinned bit for bit to the real scikit-image 0.18.3
+    (tests/golden/skimage_regionprops.npz).  Only the arithmetic the reference delegates to cuCIM / scikit-image is
+    stood in; everything from PixelDecoder.py:3062 on is the reference's own code."""
+    sys.path.insert(0, str(HERE.parents[1]))
+    from oracle import ccl_ref
+
+    def label(image, background=-1, connectivity=None, return_num=False):
+        img = np.asarray(image)
+        assert background == -1
+        if img.ndim == 3:
+            assert connectivity == 3
+            lab, n = ccl_ref.label_equal(img, True)
+        else:
+            assert connectivity == 2
+            lab, n = ccl_ref.label_equal(img[None], False)
+            lab = lab[0]
+        return (lab, n) if return_num else lab
+
+    def remove_small_objects(labels, max_size=0):
+        out = np.array(labels, copy=True)
+        counts = np.bincount(out.ravel())
+        small = np.nonzero(counts <= int(max_size))[0]
+        small = small[small != 0]
+        if small.size:
+            out[np.isin(out, small)] = 0
+        return out
+
+    def regionprops_table(label_image, intensity_image=None, properties=()):
+        labels = np.asarray(label_image)
+        inten = np.asarray(intensity_image)
+        multi = inten.ndim == labels.ndim + 1
+        chan = inten if multi else inten[..., None]
+        zero = np.zeros(labels.shape, dtype=np.float32)
+        # region_table computes every property; the distance / magnitude slots get the image when it is the one asked for
+        df = ccl_ref.region_table(labels, chan, inten if not multi else zero, inten if not multi else zero)
+        out = {}
+        for prop in properties:
+            if prop == "label":
+                out["label"] = df["label"].to_numpy(dtype=np.int64) if len(df) else np.zeros(0, np.int64)
+            elif prop == "area":
+                out["area"] = df["area"].to_numpy(dtype=np.float64) if len(df) else np.zeros(0)
+            elif prop == "centroid":
+                for k in range(labels.ndim):
+                    out[f"centroid-{k}"] = df[f"centroid-{k}"].to_numpy() if len(df) else np.zeros(0)
+            elif prop == "intensity_mean":
+                if multi:
+                    for k in range(chan.shape[-1]):
+                        out[f"intensity_mean-{k}"] = (df[f"intensity_mean-{k}"].to_numpy() if len(df)
+                                                      else np.zeros(0, chan.dtype))
+                else:
+                    out["intensity_mean"] = df["magnitude_mean"].to_numpy() if len(df) else np.zeros(0, inten.dtype)
+            elif prop == "intensity_min":
+                out["intensity_min"] = df["distance_min"].to_numpy() if len(df) else np.zeros(0, np.float32)
+            elif prop == "inertia_tensor_eigvals":
+                for k in range(3):
+                    out[f"inertia_tensor_eigvals-{k}"] = (df[f"inertia_tensor_eigvals-{k}"].to_numpy() if len(df)
+                                                          else np.zeros(0))
+            else:
+                raise KeyError(prop)
+        return out
+
+    return label, remove_small_objects, regionprops_table
+
+
+def make_extract(pdm):
+    """Reference ``_extract_barcodes`` (PixelDecoder.py:2908-3201) on the volumes of the decode fixtures ->
+    tests/golden/extract_barcodes_{16,22,2d}.npz (one array per table column)."""
+    label, rso, rpt = _skimage_standins()
+    pdm.label, pdm.remove_small_objects = label, rso
+    pdm.gpu_regionprops_table, pdm.regionprops_table = rpt, rpt
+    spacing = np.array([0.315, 0.098, 0.098], dtype=np.float32)
+    origin = np.array([2761.3, 107.81, 12.5], dtype=np.float32)
+    c2s = np.array([[1, 0, 0, 0], [0, -0.07, -1, 0], [0, -1, 0.07, 0], [0, 0, 0, 1]], dtype=np.float32)
+    ga = np.array([[1, 0, 0, 0.5], [0, 1, 0, 1.25], [0, 0, 1, -2.0], [0, 0, 0, 1]], dtype=np.float32)
+    for name, src, n_bits, is_3d, min_px, tile_idx in (
+        ("extract_barcodes_16", "decode_pixels_16", 16, True, 3, 2),
+        ("extract_barcodes_22", "decode_pixels_22", 22, True, 4, 0),
+        ("extract_barcodes_2d", "decode_pixels_16", 16, False, 2, 5),
+    ):
+        d = np.load(HERE / f"{src}.npz")
+        cb = pd.DataFrame(d["codebook_bits"].astype(np.int64), columns=[f"bit{i + 1:02d}" for i in range(n_bits)])
+        cb.insert(0, "gene_id", [str(g) for g in d["gene_ids"]])
+        dec = _bare_decoder(pdm, cb, n_bits, is_3d=is_3d)
+        dec._decoded_image = d["decoded"]
+        dec._scaled_pixel_images = d["scaled"]
+        dec._distance_image = d["distance"]
+        dec._magnitude_image = d["magnitude"]
+        dec._optimize_normalization_weights = False
+        dec._collect_chromatic_centroids = False
+        dec._tile_idx = tile_idx
+        dec._z_crop = False
+        dec._spacing, dec._origin, dec._affine, dec._camera_to_stage_affine = spacing, origin, ga, c2s
+        dec._extract_barcodes(minimum_pixels=min_px, maximum_pixels=500)
+        df = dec._df_barcodes
+        out = {"columns": np.asarray(list(df.columns)), "minimum_pixels": np.int64(min_px), "tile_idx": np.int64(tile_idx),
+               "is_3d": np.bool_(is_3d), "spacing": spacing, "origin": origin, "affine": ga, "camera_to_stage": c2s,
+               "source": np.asarray(src)}
+        for c in df.columns:
+            v = df[c].to_numpy()
+            out["col_" + c] = v.astype(str) if v.dtype == object else v
+        np.savez_compressed(HERE / f"{name}.npz", **out)
+        print(name, len(df), "transcripts;", list(df.columns)[:6], "...")
 
 
 class _FakeStore:
@@ -716,8 +853,16 @@ def main():
     if "--postdecode-only" in sys.argv:
         make_postdecode(pdm)
         return
+    if "--extract-only" in sys.argv:
+        make_extract(pdm)
+        return
+    if "--decode-only" in sys.argv:
+        make_decode(pdm)
+        make_extract(pdm)
+        return
     make_rlgc(rl)
     make_decode(pdm)
+    make_extract(pdm)
     make_normalization(pdm)
     make_registration(mv, dw, sf)
     make_sofima_jax_glue(sf)

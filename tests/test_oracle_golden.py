@@ -82,6 +82,13 @@ def test_decode_pixels_matches_reference(golden, name, is3d):
         a32, b32 = a.astype(np.float32), b.astype(np.float32)
         assert np.max(np.abs(a32 - b32)) <= 1e-3  # at most one float16 ulp apart
         assert np.mean(a != b) < 1e-3
+    # the float32 distance / magnitude the reference computed before rounding and float16 storage
+    # (PixelDecoder.py:2505-2513): the device-arithmetic oracle - which the HIP kernel equals bit for bit - is
+    # within north_star's 1e-4 of them
+    _d, _m, _di, _s, mag32, dist32 = decode_ref.decode_pixels(
+        g["lowpass"], g["decoding_matrix"], float(g["pixel_threshold"]), arith="device", return_f32=True, **kw)
+    assert np.max(np.abs(dist32 - g["distance_f32"])) <= 1e-4
+    assert np.max(np.abs(mag32 - g["magnitude_f32"])) <= 1e-4 * max(1.0, float(g["magnitude_f32"].max()))
 
 
 def test_codebook_thresholds_and_normalisation(golden):
