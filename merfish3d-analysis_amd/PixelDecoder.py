@@ -992,6 +992,9 @@ class PixelDecoder:
                     _join_gpu_workers(procs, "Iterative normalization")
                 self._optimize_normalization_weights = True
                 self._load_all_barcodes()
+                if not self._is_3D:  # per-plane calls of one molecule collapse before they vote (:4734-4740)
+                    voxel = self._datastore.voxel_size_zyx_um
+                    self._remove_duplicates_within_tile(radius_xy=voxel[-1], radius_z=voxel[0])
                 self._load_global_normalization_vectors(gpu_id=0, lowpass_sigma=lowpass_sigma)
                 self._iterative_normalization_vectors(gpu_id=0)
         finally:

@@ -43,7 +43,7 @@ class InMemoryDataStore:
         self.channel_psfs = None
         self.datastore_state = {}
         self._datastore_path = Path(datastore_path)
-        self._segmentation_root_path = None
+        self._segmentation_root_path = self._datastore_path / "segmentation"  # qi2labDataStore.py: a folder, maybe empty
         self.feature_predictor_folder_name = "feature_predictor"  # qi2labDataStore.py:1322
         self._corrected = {}      # (tile, "round"/"bit", id) -> array
         self._fiducial_decon = {}

@@ -524,6 +524,100 @@ def make_extract(pdm):
         print(name, len(df), "transcripts;", list(df.columns)[:6], "...")
 
 
+def make_optimize(pdm):
+    """The reference's ``optimize_normalization_by_decoding`` (PixelDecoder.py:4581-4757, worker :312-414) and a
+    following ``decode_one_tile(normalization_method="iterative")`` (:4471-4579), run in this process on the
+    package's in-memory datastore double: the spawn-per-GPU helpers are bound to plain calls, ``qi2labDataStore(path)``
+    to the double, the scikit-image / cuCIM calls to the pinned stand-ins above.  Saved: inputs, the vectors after the
+    global stage and after every iteration, the per-iteration transcript counts and the final tile table."""
+    import importlib
+
+    label, rso, rpt = _skimage_standins()
+    pdm.label, pdm.remove_small_objects = label, rso
+    pdm.gpu_regionprops_table, pdm.regionprops_table = rpt, rpt
+    ds_mod = importlib.import_module("merfish3d-analysis_amd.datastore")
+
+    n_bits, n_tiles, shape = 16, 2, (8, 64, 64)
+    cb = hw4_codebook(n_bits, 60, 71)
+    mat = cb.iloc[:, 1 : n_bits + 1].to_numpy(dtype=np.int64)
+    rng = np.random.default_rng(71)
+    gain = np.linspace(0.6, 1.7, n_bits)          # per-bit brightness: what the normalisation has to find
+    readouts = np.zeros((n_tiles, n_bits, *shape), dtype=np.uint16)
+    predictors = np.zeros((n_tiles, n_bits, *shape), dtype=np.float32)
+    for t in range(n_tiles):
+        vols = np.zeros((n_bits, *shape))
+        pred = np.zeros((n_bits, *shape))
+        for _ in range(140):
+            code = int(rng.integers(0, mat.shape[0]))
+            z, y, x = (int(rng.integers(1, s - 1)) for s in shape)
+            amp = rng.uniform(900, 2600)
+            for b in np.nonzero(mat[code])[0]:
+                vols[b, z, y, x] += amp * gain[b] * rng.uniform(0.85, 1.15)
+                pred[b, z, y, x] += 1.0
+        for b in range(n_bits):
+            v = sndi.gaussian_filter(vols[b], (0.9, 1.3, 1.3)) * 12.0 + 110.0
+            readouts[t, b] = np.clip(rng.poisson(v), 0, 65535).astype(np.uint16)
+            pb = np.clip(sndi.gaussian_filter(pred[b], (0.8, 1.1, 1.1)) * 14.0 + 0.03, 0.0, 1.0)
+            predictors[t, b] = (np.round(pb * 256.0) / 256.0).astype(np.float32)   # coarse values: small fixture
+
+    store = ds_mod.InMemoryDataStore(num_tiles=n_tiles, num_rounds=1, num_bits=n_bits, codebook=cb,
+                                     voxel_size_zyx_um=(0.315, 0.098, 0.098))
+    for t in range(n_tiles):
+        for b in range(n_bits):
+            store.set_corrected_image(readouts[t, b], tile=t, bit=b)
+            store.save_local_feature_predictor_image(predictors[t, b], tile=t, bit=b)
+        store.set_stage_position_zyx_um(store.tile_ids[t], np.array([10.0, 50.0 * t, 0.0], dtype=np.float32))
+    history = []
+    save = store.save_decode_normalization_vectors
+
+    def save_rec(decode_run_key, kind, normalization, background, *a, **k):
+        history.append((kind, np.asarray(normalization, dtype=np.float32).copy(),
+                        np.asarray(background, dtype=np.float32).copy()))
+        return save(decode_run_key, kind, normalization, background, *a, **k)
+
+    store.save_decode_normalization_vectors = save_rec
+
+    # process helpers -> plain calls; the worker's datastore re-open -> the double
+    counts = []
+    pdm._start_gpu_worker_process = lambda target, args, physical_gpu_id: target(*args)
+    pdm._join_gpu_workers = lambda procs, what: None
+    pdm.preload_cuda_libraries = lambda: None
+    pdm.qi2labDataStore = lambda path, validate=False: store
+    real_torch = sys.modules.get("torch")
+    sys.modules["torch"] = SimpleNamespace(cuda=SimpleNamespace(set_device=lambda i: None))
+    try:
+        dec = pdm.PixelDecoder(store, merfish_bits=n_bits, num_gpus=1, verbose=0)
+        load_all = dec._load_all_barcodes
+
+        def load_all_rec(*a, **k):
+            load_all(*a, **k)
+            counts.append(len(dec._df_barcodes_loaded))
+
+        dec._load_all_barcodes = load_all_rec
+        kw = dict(lowpass_sigma=(3.0, 1.0, 1.0), magnitude_threshold=(0.9, 10.0), minimum_pixels=3)
+        dec.optimize_normalization_by_decoding(n_iterations=3, tile_indices=[0, 1], **kw)
+        dec2 = pdm.PixelDecoder(store, merfish_bits=n_bits, num_gpus=1, verbose=0)
+        dec2.decode_one_tile(tile_idx=1, display_results=False, return_results=False, normalization_method="iterative",
+                             **kw)
+        table = dec2._df_barcodes
+    finally:
+        if real_torch is not None:
+            sys.modules["torch"] = real_torch
+        else:
+            sys.modules.pop("torch", None)
+    out = {"codebook_bits": mat.astype(np.int8), "gene_ids": np.asarray(cb["gene_id"].tolist()),
+           "readouts": readouts, "predictors": predictors, "kinds": np.asarray([h[0] for h in history]),
+           "normalization_history": np.stack([h[1] for h in history]),
+           "background_history": np.stack([h[2] for h in history]), "barcode_counts": np.asarray(counts, dtype=np.int64),
+           "decoded": dec2._decoded_image, "table_columns": np.asarray(list(table.columns))}
+    for c in table.columns:
+        v = table[c].to_numpy()
+        out["col_" + c] = v.astype(str) if v.dtype == object else v
+    np.savez_compressed(HERE / "optimize_normalization.npz", **out)
+    print("optimize:", [h[0] for h in history], counts, len(table), "transcripts in tile 1")
+    print(" final normalization", np.round(history[-1][1], 1))
+
+
 class _FakeStore:
     """Duck-typed datastore for the normalisation fixtures (identity transforms)."""
 
@@ -856,6 +950,9 @@ def main():
     if "--extract-only" in sys.argv:
         make_extract(pdm)
         return
+    if "--optimize-only" in sys.argv:
+        make_optimize(pdm)
+        return
     if "--decode-only" in sys.argv:
         make_decode(pdm)
         make_extract(pdm)
@@ -863,6 +960,7 @@ def main():
     make_rlgc(rl)
     make_decode(pdm)
     make_extract(pdm)
+    make_optimize(pdm)
     make_normalization(pdm)
     make_registration(mv, dw, sf)
     make_sofima_jax_glue(sf)
