@@ -96,6 +96,45 @@ def test_rlgc_tiled_route_and_2d_input(golden):
     assert out2.shape == g2["image"].shape and _rel_err(out2, ref2) < 5e-3
 
 
+def _phantom(shape, psf_shape, sigma, n_spots, seed):
+    rng = np.random.default_rng(seed)
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) - n // 2 for n in psf_shape], indexing="ij")
+    psf = np.exp(-0.5 * ((zz / sigma[0]) ** 2 + (yy / sigma[1]) ** 2 + (xx / sigma[2]) ** 2))
+    psf = (psf / psf.sum()).astype(np.float32)
+    vol = np.zeros(shape)
+    idx = tuple(rng.integers(0, s, size=n_spots) for s in shape)
+    np.add.at(vol, idx, rng.uniform(400, 1500, size=n_spots))
+    from scipy.ndimage import convolve
+
+    img = rng.poisson(convolve(vol, psf.astype(np.float64), mode="reflect") * 40.0 + 20.0)
+    return np.clip(img, 0, 65535).astype(np.uint16), psf
+
+
+@pytest.mark.parametrize("shape,psf_shape,padded", [((22, 70, 72), (9, 9, 9), (32, 81, 81)),
+                                                    ((52, 70, 150), (11, 9, 9), (64, 81, 162))])
+def test_solver_with_register_z_pass_matches_oracle(shape, psf_shape, padded):
+    """Padded Z = 32 / 64: the production Z pass (k_z_conv_reg: 16-point DFTs in registers around one LDS exchange),
+    the planes mirrored in LDS, the fused consensus / update tails and the register-edge X passes (81 = 9 * 9,
+    162 = 9 * 2 * 9) all inside the solver, against the independent NumPy implementation - same Philox stream."""
+    rl = pkg("utils.rlgc")
+    img, psf = _phantom(shape, psf_shape, (1.6, 1.5, 1.5), 90, seed=13)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, rinfo = rlgc_ref.rlgc(img, psf, rng="philox", return_info=True)
+    assert tuple(rinfo.padded_shape) == padded
+    out, info = rl.rlgc(img, psf, gpu_id=0, return_info=True, release_memory=False)
+    assert tuple(info.padded_shape) == padded
+    assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
+    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=2e-3)
+    assert _rel_err(out, ref) < 2e-3
+    # what DataRegistration stores: clip -> uint16 (truncation).  FFT rounding moves a value across an integer in a
+    # small fraction of voxels, never by more than one count
+    a, b = np.clip(out, 0, 65535).astype(np.uint16).astype(np.int64), np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64)
+    assert np.abs(a - b).max() <= 1 and np.mean(a != b) < 5e-3, (np.abs(a - b).max(), np.mean(a != b))
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+
+
 def test_rlgc_properties_at_medium_size():
     """Size-independent properties on a 32x256x256 volume (oracle too slow to be the checker)."""
     rl = pkg("utils.rlgc")
