@@ -16,6 +16,7 @@
 // traffic except one half-wave swap.
 
 #include <cmath>
+#include <cstdlib>
 
 #include "m3d_common.h"
 #include "m3d_index.h"
@@ -167,10 +168,15 @@ void gauss_strided(const float *in, float *out, int64_t n_lines, int64_t inner,
 // ---------------------------------------------------------------------------------------
 // cp.round(x, 5) of a float32 (CuPy evaluates in double), then the float16 store
 // (PixelDecoder.py:2621-2632 into the float16 arrays of :2540-2543).
+// The product v * 1e5 is exact in double (24 x 17 significant bits) and rint() of it is an integer q; for |q| < 2^24
+// the quotient is taken in float32: float32(double(q) / 1e5) == float32(q) / 100000.0f, because rounding a quotient
+// first to 53 bits and then to 24 is innocuous (53 >= 2 * 24 + 2) - one correctly rounded float32 division instead
+// of a double-precision one, same bits.
 __device__ __forceinline__ uint16_t round5_f16(float v)
 {
-    const double r = rint((double)v * 1e5) / 1e5;
-    return f32_to_f16_bits((float)r);
+    const double q = rint((double)v * 1e5);
+    if (fabs(q) < 16777216.0) return f32_to_f16_bits(rn_div((float)q, 100000.0f));
+    return f32_to_f16_bits((float)(q / 1e5));
 }
 
 struct DecodeArgs {
@@ -199,8 +205,9 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
     extern __shared__ float lds[];
     const int NT = a.NT;
     float *afrag = lds;                      // [NT][KS][64]
-    float *yn = afrag + (size_t)NT * KS * 64;  // [NT*32] codeword squared norms
+    float *yn = afrag + (size_t)NT * KS * 64;  // [NT*32] codeword squared norms, in epilogue order (see ynq)
     int *excl = (int *)(yn + NT * 32);       // [NT*32] 1 if excluded
+    const float4 *ynq = (const float4 *)yn;  // [NT][2 halves][4 row groups] x 4 rows
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int half = lane >> 5;
@@ -219,7 +226,11 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
                 const float v = a.codebook[(size_t)c * a.B + b];
                 acc = rn_fma(v, v, acc);
             }
-        yn[c] = acc;
+        // slot of codeword c = 32 t + j + 8 g + 4 h  ->  ((t * 2 + h) * 4 + g) * 4 + j
+        {
+            const int t = c >> 5, w = c & 31, j = w & 3, h = (w >> 2) & 1, gq = w >> 3;
+            yn[(((t * 2 + h) * 4 + gq) << 2) + j] = c < a.C ? acc : INFINITY;
+        }
         int e = 0;
         for (int j = 0; j < a.n_excluded; ++j) e |= (a.excluded[j] == c);
         excl[c] = e;
@@ -237,6 +248,15 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
     const int64_t n_trips = (a.N + 63) / 64;
     const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
     const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // The pixel of the NEXT trip is requested while the current one goes through the matrix cores: with four waves
+    // per SIMD and no prefetch the waves sat in s_waitcnt for 43 % of their cycles (profiles/r02_pmc_decode.json).
+    // Clamped addresses, so the request is unconditional and lands in the loop-carried registers.
+    float raw[2 * KS];
+    {
+        const int64_t p0 = min(wave_global * 64 + lane, a.N - 1);
+#pragma unroll
+        for (int b = 0; b < 2 * KS; ++b) raw[b] = a.stack[(size_t)min(b, a.B - 1) * a.N + p0];
+    }
     for (int64_t trip = wave_global; trip < n_trips; trip += wave_stride) {
         const int64_t p = trip * 64 + lane;
         const bool valid = p < a.N;
@@ -244,12 +264,25 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
         float s[2 * KS];
 #pragma unroll
         for (int b = 0; b < 2 * KS; ++b) {
-            float v = (valid && b < a.B) ? a.stack[(size_t)b * a.N + p] : 0.0f;
+            float v = (valid && b < a.B) ? raw[b] : 0.0f;
             if (!a.prenormalized) {
                 if (use_norm) v = rn_div(rn_sub(v, bk[b]), nm[b]);
                 v = fminf(fmaxf(v, 0.0f), 1.0f);
             }
             s[b] = (b < a.B) ? v : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int64_t pn = min((trip + wave_stride) * 64 + lane, a.N - 1);
+#pragma unroll
+            for (int b = 0; b < 2 * KS; ++b) raw[b] = a.stack[(size_t)min(b, a.B - 1) * a.N + pn];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the clipped traces leave now (float16), so their registers are free during the matrix phase
+        if (valid) {
+#pragma unroll
+            for (int b = 0; b < 2 * KS; ++b)
+                if (b < a.B) a.scaled_f16[(size_t)b * a.N + p] = round5_f16(s[b]);
         }
         // ---- L2 norm over bits, sequential like add.reduce(axis=0) (:2459-2462)
         float acc = rn_mul(s[0], s[0]);
@@ -288,20 +321,31 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
 #pragma unroll
                 for (int k = 0; k < KS; ++k)
                     d = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k * 64], bop[k], d, 0, 0, 0);
-                // d[r] = <codeword 32t + row(r), pixel>, row(r) = (r&3) + 8(r>>2) + 4*half
+                // d[r] = <codeword 32t + row(r), pixel>, row(r) = (r&3) + 8(r>>2) + 4*half.  The four codeword norms
+                // of a row group are one 16-byte LDS read (ynq: [tile][half][group][4], +inf for rows past C, so
+                // padding rows lose every comparison without a test).
+                const float4 *yq = ynq + (t * 2 + half) * 4;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const float tt = rn_add(xn_t, yn[c]);
-                    const float d2 = fmaxf(rn_sub(tt, rn_mul(2.0f, d[r])), 0.0f);
-                    if (c < a.C && d2 < best2) {
-                        // d = sqrt_rn(d2) is monotone: a smaller d2 wins unless it rounds to
-                        // the same distance, where the earlier codeword must be kept
-                        if (d2 >= best2 * 0.9999995f && rn_sqrt(d2) == rn_sqrt(best2)) {
-                            best2 = d2;
-                        } else {
-                            best2 = d2;
-                            besti = c;
+                for (int gq = 0; gq < 4; ++gq) {
+                    const float4 y4 = yq[gq];
+                    const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * gq + j;
+                        const int c = 32 * t + j + 8 * gq + 4 * half;
+                        const float tt = rn_add(xn_t, yv[j]);
+                        const float d2 = fmaxf(rn_fma(-2.0f, d[r], tt), 0.0f);  // 2 d is exact: == tt - 2 d rounded once
+                        const float b2o = best2;
+                        const int bio = besti;
+                        const bool lt = d2 < b2o;
+                        best2 = lt ? d2 : b2o;
+                        besti = lt ? c : bio;
+                        // d = sqrt_rn(d2) is monotone: a smaller d2 wins unless it rounds to the same distance, where
+                        // the earlier codeword must be kept.  Such near ties are rare: one wave-uniform test per
+                        // element, the square roots only when some lane has one.
+                        const bool near = lt && d2 >= b2o * 0.9999995f;
+                        if (__builtin_amdgcn_ballot_w64(near)) {
+                            if (near && rn_sqrt(d2) == rn_sqrt(b2o)) besti = bio;
                         }
                     }
                 }
@@ -331,9 +375,6 @@ __global__ __launch_bounds__(256) void k_decode(DecodeArgs a)
             a.distance_f16[p] = round5_f16(my_d);
             if (a.magnitude_f32) a.magnitude_f32[p] = mag;
             if (a.distance_f32) a.distance_f32[p] = my_d;
-#pragma unroll
-            for (int b = 0; b < 2 * KS; ++b)
-                if (b < a.B) a.scaled_f16[(size_t)b * a.N + p] = round5_f16(s[b]);
         }
     }
 }
@@ -485,7 +526,9 @@ int m3d_decode_pixels(const float *stack, int32_t B, int64_t N, const float *bac
     a.hi = magnitude_hi;
     const int64_t trips = (N + 63) / 64;
     int64_t blocks = (trips + 3) / 4;
-    if (blocks > 256 * 4) blocks = 256 * 4;
+    // blocks per CU of the grid-stride launch: 116 registers per lane allow four waves per SIMD = four resident blocks
+    static const int per_cu = [] { const char *e = getenv("M3D_DECODE_BLOCKS_PER_CU"); return e ? atoi(e) : 4; }();
+    if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;
     hipStream_t st = (hipStream_t)stream;
     if (KS == 8)
         hipLaunchKernelGGL(k_decode<8>, dim3((int)blocks), dim3(256), lds, st, a);
