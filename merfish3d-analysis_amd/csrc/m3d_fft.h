@@ -47,16 +47,25 @@ struct AxisPlan {
     const int *pos;         // device: position of frequency k after the DIF pass
 };
 
+// Complex arithmetic on the two-lane vector type: the passes are instruction-issue bound (one wave instruction per
+// four cycles per SIMD, whatever its kind), and v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 handle real and imaginary
+// part in one issue.  Written on HIP's float2 operators (native ext_vector arithmetic) so that the compiler selects
+// the packed forms with their op_sel / neg modifiers instead of relying on the SLP vectoriser.
+__device__ __forceinline__ float2 swap_xy(float2 a) { return make_float2(a.y, a.x); }
+__device__ __forceinline__ float2 xx(float2 a) { return make_float2(a.x, a.x); }
+__device__ __forceinline__ float2 yy(float2 a) { return make_float2(a.y, a.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (-b.y, b.x)
+    return xx(a) * b + yy(a) * make_float2(-b.y, b.x);
 }
 __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)  // a * conj(b)
 {
-    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+    // (a.x b.x + a.y b.y, a.y b.x - a.x b.y) = xx(b) * a + yy(b) * (a.y, -a.x)
+    return xx(b) * a + yy(b) * make_float2(a.y, -a.x);
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
 __device__ __forceinline__ float2 rot90(float2 a)
@@ -67,28 +76,28 @@ __device__ __forceinline__ float2 rot90(float2 a)
 template <bool INV>
 __device__ __forceinline__ float2 ctw(float2 a, float c, float s)
 {
-    return INV ? make_float2(a.x * c - a.y * s, a.x * s + a.y * c)
-               : make_float2(a.x * c + a.y * s, a.y * c - a.x * s);
+    // forward: (a.x c + a.y s, a.y c - a.x s) = a c + (a.y, -a.x) s ; inverse: a c + (-a.y, a.x) s
+    return a * make_float2(c, c) + rot90<INV>(a) * make_float2(s, s);
 }
 
 template <bool INV>
 __device__ __forceinline__ void dft2(float2 &a, float2 &b)
 {
     const float2 t = a;
-    a = cadd(t, b);
-    b = csub(t, b);
+    a = t + b;
+    b = t - b;
 }
 template <bool INV>
 __device__ __forceinline__ void dft3(float2 &v0, float2 &v1, float2 &v2)
 {
     const float s = 0.86602540378443864676f;
-    const float2 t1 = cadd(v1, v2);
-    const float2 t2 = make_float2(v0.x - 0.5f * t1.x, v0.y - 0.5f * t1.y);
-    const float2 d = csub(v1, v2);
-    const float2 t3 = rot90<INV>(make_float2(s * d.x, s * d.y));
-    v0 = cadd(v0, t1);
-    v1 = cadd(t2, t3);
-    v2 = csub(t2, t3);
+    const float2 t1 = v1 + v2;
+    const float2 t2 = v0 - t1 * make_float2(0.5f, 0.5f);
+    const float2 d = (v1 - v2) * make_float2(s, s);
+    const float2 t3 = rot90<INV>(d);
+    v0 = v0 + t1;
+    v1 = t2 + t3;
+    v2 = t2 - t3;
 }
 template <bool INV>
 __device__ __forceinline__ void dft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)

@@ -68,6 +68,7 @@ struct FftConvPlan {
     int zreg;  // Zp / 16 when the register variant of the Z pass applies (Zp = 32, 64, 128, 256), else 0
     int xreg;  // X passes with register edge stages (radix list 9 ... 9, Xp / 9 <= 254, 256 threads)
     int lch;   // log2 of the rows per y chunk of the spectrum layout
+    int ystatic;  // the Y pass runs its static-geometry build
 };
 
 }  // namespace m3d
@@ -812,37 +813,36 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
                 valid[r] = yr[r] >= g.out.y0 && yr[r] < y_hi;
                 rowo[r] = ((int64_t)z * g.Yp + (valid[r] ? yr[r] : g.out.y0)) * N;
             }
-            float av[2][9], bv[2][9];
-            if constexpr (EPI != m3d::ConvEpilogue::kNone) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        av[r][q] = ep.a[rowo[r] + n];
-                        bv[r][q] = ep.b[rowo[r] + n];
-                    }
-                }
-            }
             float2 v[9];
             const float2 *row = lds_ir + bi * N + tid;
             v[0] = row[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
             dft9<true>(v);
+            // one output row after the other (tail operands of one row = 18 registers), after the butterflies
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int n = tid + S * q;
-                if (n < g.out.x0 || n >= x_hi) continue;
+            for (int r = 0; r < 2; ++r) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!valid[r]) continue;
+                float av[9], bv[9];
+                if constexpr (EPI != m3d::ConvEpilogue::kNone) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if (!valid[r]) continue;
+                    for (int q = 0; q < 9; ++q) {
+                        const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
+                        av[q] = ep.a[rowo[r] + n];
+                        bv[q] = ep.b[rowo[r] + n];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 9; ++q) {
+                    const int n = tid + S * q;
+                    if (n < g.out.x0 || n >= x_hi) continue;
                     const float c = r ? v[q].y : v[q].x;
                     if constexpr (EPI == m3d::ConvEpilogue::kNone) {
                         dst[rowo[r] + n] = c;
                     } else if constexpr (EPI == m3d::ConvEpilogue::kUpdate) {
-                        const float old = av[r][q];
-                        const float nw = c < 0.0f ? old : old * bv[r][q];
+                        const float old = av[q];
+                        const float nw = c < 0.0f ? old : old * bv[q];
                         ep.o1[rowo[r] + n] = nw;
                         updated += (c >= 0.0f) ? 1ull : 0ull;
                         mx = fmaxf(mx, nw);
@@ -914,41 +914,37 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     if (tid < S) {
         float2 w[9];
         edge_twiddles(w, ax.tw, tid);
-        float2 v0[9], v1[9];
-        const float2 *row = lds_dr + tid;
-        v0[0] = row[0];
-        v1[0] = row[N];
-#pragma unroll
-        for (int q = 1; q < 9; ++q) {
-            v0[q] = cmul_conj(row[S * q], w[q]);
-            v1[q] = cmul_conj(row[N + S * q], w[q]);
-        }
-        dft9<true>(v0);
-        dft9<true>(v1);
         const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
-        const bool c0 = z_core && y0 >= ep.core.y0 && y0 < ep.core.y0 + ep.core.ny;
-        const bool c1 = z_core && row1 && y0 + 1 >= ep.core.y0 && y0 + 1 < ep.core.y0 + ep.core.ny;
         float2 pk[9];
+        // one row after the other: both rows' butterflies in flight at once cost 40 registers more than there are
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int n = tid + S * q;
-            const bool xc = n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx;
-            float prod[2];
+        for (int r = 0; r < 2; ++r) {
+            float2 v[9];  // (HTratio1 raw, HTratio2 raw) of row y0 + r at x = tid + S q
+            const float2 *row = lds_dr + r * N + tid;
+            v[0] = row[0];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float2 v = r ? v1[q] : v0[q];  // (HTratio1 raw, HTratio2 raw)
+            for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
+            dft9<true>(v);
+            const bool live = r == 0 || row1;
+            const bool yc = z_core && live && y0 + r >= ep.core.y0 && y0 + r < ep.core.y0 + ep.core.ny;
+            const int64_t rr = r ? r1 : r0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int n = tid + S * q;
                 const float un = r ? un1[q] : un0[q];
-                const float h1 = v.x / un, h2 = v.y / un;
-                prod[r] = (h1 - 1.0f) * (h2 - 1.0f);
-                if (r == 0 || row1) {
+                const float h1 = v[q].x / un, h2 = v[q].y / un;
+                const float prod = (h1 - 1.0f) * (h2 - 1.0f);
+                if (live) {
                     const float hs = h1 + h2;
                     mn = fminf(mn, hs);
                     mx = fmaxf(mx, hs);
-                    if ((r ? c1 : c0) && xc) ep.o2[(r ? r1 : r0) + n] = hs;
-                    if constexpr (!CHAIN) ep.o1[(r ? r1 : r0) + n] = prod[r];
+                    if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[rr + n] = hs;
+                    if constexpr (!CHAIN) ep.o1[rr + n] = prod;
                 }
+                if (r == 0) pk[q] = make_float2(prod, 0.0f);
+                else if (row1) pk[q].y = prod;
             }
-            pk[q] = make_float2(prod[0], row1 ? prod[1] : 0.0f);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (CHAIN) {
             // first forward stage of the packed product rows, from the registers that just produced them; the LDS
@@ -1018,6 +1014,116 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
     } else {
         for (int i = slo + tid; i < shi; i += nt) pl[tile_elem(g, kt, i)] = lds_y[i];
     }
+}
+
+// ---------------------------------------------------------------- Y pass, static geometry
+// Counters (profiles/r02_pmc_sq_rlgc_before.json) put every pass at about one wave instruction of ANY kind per four
+// cycles per SIMD: (VALU + SALU + LDS + VMEM instructions) x 4 / 1024 SIMDs reproduces the kernel durations within
+// 10 %.  The passes are instruction-issue bound, and in the generic kernels more than half of the instructions are
+// index arithmetic on run-time geometry (k_y_pass: 821 scalar + ~250 integer vector instructions around ~350
+// floating-point ones).  For the headline geometry the whole pass is compiled with every extent, stride, radix and
+// chunk size as a constant: the stage loops unroll, divisions become shifts and immediates.
+template <int R, bool INV, int N, int M, int TWc, int NT_>
+__device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__restrict__ tw, int tid)
+{
+    // four interleaved transforms per butterfly item (G = TW = 4): element k of transform b at data[k * TW + b]
+    constexpr int sub = M / R, per_fft = N / R, twstep = N / M, step = sub * TWc;
+#pragma unroll 1
+    for (int t = tid; t < per_fft; t += NT_) {
+        const int blk = t / sub, j = t - blk * sub;
+        float2 w[R];
+        const int j1 = j * twstep;
+        if constexpr (R == 9) {
+            w[1] = tw[j1];
+            w[2] = tw[2 * j1];
+            w[4] = tw[4 * j1];
+            w[3] = cmul(w[1], w[2]);
+            w[5] = cmul(w[1], w[4]);
+            w[6] = cmul(w[2], w[4]);
+            w[7] = cmul(w[3], w[4]);
+            w[8] = cmul(w[4], w[4]);
+        } else {
+            w[1] = tw[j1];
+            if constexpr (R >= 3) w[2] = cmul(w[1], w[1]);
+            if constexpr (R >= 4) w[3] = cmul(w[1], w[2]);
+        }
+        float2 *p0 = data + (blk * M + j) * TWc;
+        const int rot = t >> 3;  // lanes 8 apart sit 256 B apart: rotate the member each lane starts with
+#pragma unroll
+        for (int it = 0; it < TWc; ++it) {
+            float2 *p = p0 + ((it + rot) & (TWc - 1));
+            float2 v[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) v[q] = p[q * step];
+            if (INV) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = cmul_conj(v[q], w[q]);
+                dft_r<R, true>(v);
+            } else {
+                dft_r<R, false>(v);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) p[q * step] = v[q];
+        }
+    }
+}
+
+// YP = R0 * R1 * R2 * R3 (R3 may be 1), TW = 4, 2^LCH rows per chunk, NT_ threads.
+template <bool INV, int YP, int R0, int R1, int R2, int R3, int LCH, int NT_>
+__global__ __launch_bounds__(NT_) void k_y_pass_static(float2 *__restrict__ spec, ConvGeo g, const float2 *__restrict__ tw)
+{
+    extern __shared__ float2 lds_ys[];
+    constexpr int TWc = 4, n = YP * TWc, CH = 1 << LCH;
+    const int tid = threadIdx.x;
+    const m3d::ConvBox &bx = INV ? g.out : g.in;
+    const int z = bx.z0 + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
+    float2 *pl = spec + (int64_t)z * g.plane;
+    const int lo = INV ? 0 : bx.y0 * TWc, hi = INV ? n : (bx.y0 + bx.ny) * TWc;    // load range (elements)
+    const int slo = INV ? bx.y0 * TWc : 0, shi = INV ? (bx.y0 + bx.ny) * TWc : n;  // store range
+    auto elem = [&](int i) {  // 16-byte item i (= half a row) of this tile -> in-plane element offset
+        const int y = i >> 1, y0c = y & ~(CH - 1);
+        const int rows_c = min(CH, YP - y0c);
+        return ((y0c * g.nT + (y - y0c)) << 2) + ((kt * rows_c) << 2) + ((i & 1) << 1);
+    };
+    float4 *l4 = (float4 *)lds_ys;
+    constexpr int kU = M3D_KU_Y;
+    for (int i0 = tid; i0 < n / 2; i0 += NT_ * kU) {
+        float4 v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) v[u] = *(const float4 *)(pl + elem(min(max(i0 + u * NT_, lo / 2), hi / 2 - 1)));
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int i = i0 + u * NT_;
+            if (i < n / 2) l4[i] = (i >= lo / 2 && i < hi / 2) ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    if (!INV) {
+        y_stage_static<R0, false, YP, YP, TWc, NT_>(lds_ys, tw, tid);
+        __syncthreads();
+        y_stage_static<R1, false, YP, YP / R0, TWc, NT_>(lds_ys, tw, tid);
+        __syncthreads();
+        y_stage_static<R2, false, YP, YP / (R0 * R1), TWc, NT_>(lds_ys, tw, tid);
+        __syncthreads();
+        if constexpr (R3 > 1) {
+            y_stage_static<R3, false, YP, YP / (R0 * R1 * R2), TWc, NT_>(lds_ys, tw, tid);
+            __syncthreads();
+        }
+    } else {
+        if constexpr (R3 > 1) {
+            y_stage_static<R3, true, YP, R3, TWc, NT_>(lds_ys, tw, tid);
+            __syncthreads();
+        }
+        y_stage_static<R2, true, YP, R3 * R2, TWc, NT_>(lds_ys, tw, tid);
+        __syncthreads();
+        y_stage_static<R1, true, YP, R3 * R2 * R1, TWc, NT_>(lds_ys, tw, tid);
+        __syncthreads();
+        y_stage_static<R0, true, YP, YP, TWc, NT_>(lds_ys, tw, tid);
+        __syncthreads();
+    }
+    for (int i = slo / 2 + tid; i < shi / 2; i += NT_) *(float4 *)(pl + elem(i)) = l4[i];
 }
 
 // Y forward pass of a volume given by its core rows only (symmetric extension along y and z): plane z is
@@ -1430,6 +1536,9 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
                p->ax.radix[p->ax.nstages - 1] == 9 && p->xthreads == 256 && p->dual_threads == 256 &&
                p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 256 && Xp / 9 <= 256)
                   ? 1 : 0;
+    p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && p->ythreads == 768 &&
+                  p->gy == 4 && p->ay.nstages == 4 && p->ay.radix[0] == 9 && p->ay.radix[1] == 9 &&
+                  p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 1 : 0;
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -1499,6 +1608,8 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 2>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<1>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
@@ -1559,6 +1670,20 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
 }
 
+// Y pass: the static-geometry build when the plan is the headline one (2187 = 9 * 9 * 9 * 3, TW 4, 128-row chunks,
+// 768 threads, four transforms per item), else the generic kernel.
+template <bool INV>
+static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, int nz, hipStream_t st)
+{
+    const dim3 grid((unsigned)(nz * p->nT)), block(p->ythreads);
+    if (p->ystatic) {
+        hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 768>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    } else if (p->rset_y)
+        hipLaunchKernelGGL((k_y_pass<INV, 1>), grid, block, p->lds_y, st, spec, g, p->ay);
+    else
+        hipLaunchKernelGGL((k_y_pass<INV, 0>), grid, block, p->lds_y, st, spec, g, p->ay);
+}
+
 static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spec, const ConvGeo &g, int groups,
                              hipStream_t st)
 {
@@ -1603,10 +1728,7 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         launch_x_forward(p, src, spec, g, groups, st);
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
     }
-    if (p->rset_y)
-        hipLaunchKernelGGL((k_y_pass<false, 1>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
-    else
-        hipLaunchKernelGGL((k_y_pass<false, 0>), dim3((unsigned)(g.in.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+    launch_y_pass<false>(p, spec, g, g.in.nz, st);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -1646,10 +1768,7 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     launch_z(p, spec, otf, g, mode, scale, st);
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
-    if (p->rset_y)
-        hipLaunchKernelGGL((k_y_pass<true, 1>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
-    else
-        hipLaunchKernelGGL((k_y_pass<true, 0>), dim3((unsigned)(g.out.nz * p->nT)), dim3(p->ythreads), p->lds_y, st, spec, g, p->ay);
+    launch_y_pass<true>(p, spec, g, g.out.nz, st);
     if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
