@@ -69,6 +69,7 @@ struct FftConvPlan {
     int xreg;  // X passes with register edge stages (radix list 9 ... 9, Xp / 9 <= 254, 256 threads)
     int lch;   // log2 of the rows per y chunk of the spectrum layout
     int ystatic;  // the Y pass runs its static-geometry build
+    int xstatic;  // the register-edge X passes run their static-geometry builds (NS = 2187)
 };
 
 }  // namespace m3d
@@ -512,10 +513,40 @@ __device__ __forceinline__ void edge_twiddles(float2 (&w)[9], const float2 *__re
     w[8] = cmul(w[4], w[4]);
 }
 
+// Static geometry (see k_y_pass_static): NS = 2187 fixes Xp = Yp = 2187, TW = 4, four rows per X block, 128-row
+// chunks and the radix list 9 * 9 * 3 * 9, so the index arithmetic of a pass folds into immediates.  NS = 0: run time.
+template <int NS>
+__device__ __forceinline__ ConvGeo static_geo(const ConvGeo &g)
+{
+    ConvGeo s = g;
+    if constexpr (NS == 2187) {
+        s.Xp = 2187;
+        s.Yp = 2187;
+        s.Xc = 1094;
+        s.TW = 4;
+        s.lTW = 2;
+        s.nT = 274;
+        s.RB = 4;
+        s.lNB = 1;
+        s.lCH = 7;
+        s.lDR = 1;
+        s.GX = 4;
+        s.plane = (int64_t)274 * 2187 * 4;
+    }
+    return s;
+}
+
 // middle stages of the DIF forward transform (block sizes S ... 9 exclusive of the two register stages)
-template <int RSET>
+template <int RSET, int NS = 0>
 __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, int nb, int N, int tid, int nt, int gmax)
 {
+    if constexpr (NS == 2187) {
+        lds_stage<9, false>(lds, 2187, 243, 1, nb, 2187, ax.tw, tid, 256, 4);
+        __syncthreads();
+        lds_stage<3, false>(lds, 2187, 27, 1, nb, 2187, ax.tw, tid, 256, 4);
+        __syncthreads();
+        return;
+    }
     int M = N / 9;
     for (int s = 1; s < ax.nstages - 1; ++s) {
         const int r = ax.radix[s];
@@ -524,9 +555,16 @@ __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, 
         __syncthreads();
     }
 }
-template <int RSET>
+template <int RSET, int NS = 0>
 __device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, int nb, int N, int tid, int nt, int gmax)
 {
+    if constexpr (NS == 2187) {
+        lds_stage<3, true>(lds, 2187, 27, 1, nb, 2187, ax.tw, tid, 256, 4);
+        __syncthreads();
+        lds_stage<9, true>(lds, 2187, 243, 1, nb, 2187, ax.tw, tid, 256, 4);
+        __syncthreads();
+        return;
+    }
     int M = 9;
     for (int s = ax.nstages - 2; s >= 1; --s) {
         const int r = ax.radix[s];
@@ -662,12 +700,13 @@ __device__ __forceinline__ void pair_offsets(const ConvGeo &g, int S, int kp, in
     for (int d = 0; d < 4; ++d) off[5 + d] = tile_term(g, k2p + S * d, rows_c);  // k2p == kp: loaded but unused
 }
 
-template <int RSET>
+template <int RSET, int NS = 0>
 __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restrict__ src, float2 *__restrict__ spec,
-                                                      ConvGeo g, AxisPlan ax)
+                                                      ConvGeo g_, AxisPlan ax)
 {
     extern __shared__ float2 lds_fr[];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const ConvGeo g = static_geo<NS>(g_);
+    const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
     const int yg0 = (g.in.y0 / g.RB) * g.RB, y_hi = g.in.y0 + g.in.ny, x_hi = g.in.x0 + g.in.nx;
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
@@ -728,7 +767,7 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
     __syncthreads();
     M3D_STAMP(5);
 #if !defined(M3D_XF_NOMID) && !defined(M3D_XF_COPYONLY)
-    middle_forward<RSET>(lds_fr, ax, nb, N, tid, nt, g.GX);
+    middle_forward<RSET, NS>(lds_fr, ax, nb, N, tid, nt, g.GX);
 #endif
     M3D_STAMP(6);
     {
@@ -759,15 +798,16 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
 }
 
 // Fused tails run on the registers of the last inverse stage: thread t holds x[t + S q] of both packed rows.
-template <int RSET, int EPI>
+template <int RSET, int EPI, int NS = 0>
 __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restrict__ spec, float *__restrict__ dst,
-                                                      ConvGeo g, AxisPlan ax, m3d::ConvEpilogue ep)
+                                                      ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
     extern __shared__ float2 lds_ir[];
     __shared__ float smf[4];
     __shared__ unsigned long long smu[4];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const ConvGeo g = static_geo<NS>(g_);
+    const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
     const int yg0 = (g.out.y0 / g.RB) * g.RB, y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
@@ -798,7 +838,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
         inverse_pair_merge(lds_ir + pbi * N, S, N, kp, u1 / 9, u2 / 9, Av, Bv);
     }
     __syncthreads();
-    middle_inverse<RSET>(lds_ir, ax, nb, N, tid, nt, g.GX);
+    middle_inverse<RSET, NS>(lds_ir, ax, nb, N, tid, nt, g.GX);
     float mx = -INFINITY, dmax = 0.0f;
     unsigned long long updated = 0;
     if (tid < S) {
@@ -867,15 +907,16 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
 // Dual X inverse pass (two spectra -> HTratio1, HTratio2 of two rows) with the consensus arithmetic in registers and,
 // CHAIN, the product's X forward transform started from the same registers: the element the last inverse stage hands
 // thread t at x = t + S q is the element the first forward stage takes from it.
-template <int RSET, bool CHAIN>
+template <int RSET, bool CHAIN, int NS = 0>
 __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
-                                                           const float2 *__restrict__ spec2, ConvGeo g, AxisPlan ax,
+                                                           const float2 *__restrict__ spec2, ConvGeo g_, AxisPlan ax,
                                                            m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
     extern __shared__ float2 lds_dr[];
     __shared__ float smf[4];
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const ConvGeo g = static_geo<NS>(g_);
+    const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
     const int N = g.Xp, S = N / 9, I = S / 2 + 1;
     const int groups = (g.Yp + 1) / 2;
     const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * 2;
@@ -909,7 +950,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         }
     }
     __syncthreads();
-    middle_inverse<RSET>(lds_dr, ax, 2, N, tid, nt, g.GX);
+    middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
     float mn = INFINITY, mx = -INFINITY;
     if (tid < S) {
         float2 w[9];
@@ -965,7 +1006,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     }
     if constexpr (CHAIN) {
         __syncthreads();
-        middle_forward<RSET>(lds_dr, ax, 1, N, tid, nt, g.GX);
+        middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
         if (tid < I) {
             float2 c1[9], c2[9];
             forward_pair_load(lds_dr, pu1, pu2, c1, c2);
@@ -1301,7 +1342,10 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
         const int z = l + L * m;
         const bool inside = z >= g.in.z0 && z < zin_hi;
         // outside the input's planes: zero, or (zmirror) the plane it mirrors - the same data again, never zero
-        const int zs = inside ? z : (g.zmirror ? sym_src(z, g.in.z0, g.in.nz) : g.in.z0);
+        // zmirror == 2: the pad on either side is no deeper than the core, one reflection and no modulo
+        const int zs = inside ? z
+                       : (g.zmirror == 2 ? (z < g.in.z0 ? 2 * g.in.z0 - 1 - z : 2 * zin_hi - 1 - z)
+                                         : (g.zmirror ? sym_src(z, g.in.z0, g.in.nz) : g.in.z0));
         v[m] = col[(int64_t)zs * g.plane];
         if (!live || !(inside || g.zmirror)) v[m] = make_float2(0.f, 0.f);
     }
@@ -1539,6 +1583,9 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && p->ythreads == 768 &&
                   p->gy == 4 && p->ay.nstages == 4 && p->ay.radix[0] == 9 && p->ay.radix[1] == 9 &&
                   p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 1 : 0;
+    p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
+                  p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&
+                  p->ax.radix[2] == 3) ? 1 : 0;
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -1688,7 +1735,9 @@ static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spe
                              hipStream_t st)
 {
     const dim3 grid((unsigned)(g.in.nz * groups)), block(p->xthreads);
-    if (p->xreg) {
+    if (p->xstatic) {
+        hipLaunchKernelGGL((k_x_forward_reg<1, 2187>), grid, block, p->lds_x, st, src, spec, g, p->ax);
+    } else if (p->xreg) {
         if (p->rset_x)
             hipLaunchKernelGGL(k_x_forward_reg<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
         else
@@ -1765,6 +1814,7 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
     ConvGeo g = geo_of(p, (mirrored && p->zmirror) ? mirror_box : in_box, out_box);
     g.zmirror = (mirrored && p->zmirror) ? 1 : 0;
+    if (g.zmirror && g.in.z0 <= g.in.nz && p->Zp - (g.in.z0 + g.in.nz) <= g.in.nz) g.zmirror = 2;  // single reflection
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
     launch_z(p, spec, otf, g, mode, scale, st);
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
@@ -1786,7 +1836,12 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
     const int nb = p->dual_rows;
     const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
     const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
-    if (p->xreg) {
+    if (p->xstatic) {
+        if (chain_forward)
+            hipLaunchKernelGGL((k_x_inverse_dual_reg<1, true, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+        else
+            hipLaunchKernelGGL((k_x_inverse_dual_reg<1, false, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+    } else if (p->xreg) {
 #define M3D_LAUNCH_XD(RS, CH) \
     hipLaunchKernelGGL((k_x_inverse_dual_reg<RS, CH>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue)
         if (chain_forward) {
@@ -1830,7 +1885,12 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
     hipLaunchKernelGGL((k_x_inverse<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
 #define M3D_LAUNCH_XIR(RS, EP) \
     hipLaunchKernelGGL((k_x_inverse_reg<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
-    if (p->xreg && ep.kind != ConvEpilogue::kConsensus) {
+    if (p->xstatic && ep.kind != ConvEpilogue::kConsensus) {
+        if (ep.kind == ConvEpilogue::kUpdate)
+            hipLaunchKernelGGL((k_x_inverse_reg<1, 2, 2187>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+        else
+            hipLaunchKernelGGL((k_x_inverse_reg<1, 0, 2187>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+    } else if (p->xreg && ep.kind != ConvEpilogue::kConsensus) {
         if (p->rset_x) {
             if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XIR(1, 2);
             else M3D_LAUNCH_XIR(1, 0);

@@ -59,8 +59,9 @@ def test_simulation_f1_sofima_not_below_affine(tmp_path):
         res = sim.calculate_F1(store, gt, search_radius=1.0)
         scores[mode] = res
         print(f"\\n{mode}: {res}")
-    # registration recovered the planted round shifts (pull = + shift)
-    np.testing.assert_allclose(shifts_found["affine"], np.asarray(SHIFTS), atol=0.4)
+    # registration recovered the planted round shifts (pull = + shift) to within the smooth warp that rides on them
+    # (amplitude 1.2 px: the rigid estimate locks onto the dominant displacement, the residual is SOFIMA's job)
+    np.testing.assert_allclose(shifts_found["affine"], np.asarray(SHIFTS), atol=1.2 + 0.35)
     f1a, f1s = scores["affine"]["F1 Score"], scores["sofima"]["F1 Score"]
     assert f1a > 0.6, scores
     assert round(f1s, 3) >= round(f1a, 3), scores   # tests/test_simulation_example_pipeline.py:1308-1318
