@@ -1167,6 +1167,58 @@ __global__ __launch_bounds__(NT_) void k_y_pass_static(float2 *__restrict__ spec
     for (int i = slo / 2 + tid; i < shi / 2; i += NT_) *(float4 *)(pl + elem(i)) = l4[i];
 }
 
+// Static-geometry form of k_y_forward_mirror (below): core rows of plane sym_src(z) -> all rows of plane z.
+template <int YP, int R0, int R1, int R2, int R3, int LCH, int NT_>
+__global__ __launch_bounds__(NT_) void k_y_forward_mirror_static(const float2 *__restrict__ src, float2 *__restrict__ dst,
+                                                                ConvGeo g, const float2 *__restrict__ tw)
+{
+    extern __shared__ float2 lds_yms[];
+    constexpr int TWc = 4, n = YP * TWc, CH = 1 << LCH;
+    const int tid = threadIdx.x;
+    const int z = (g.zmirror ? g.mir.z0 : 0) + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
+    const int zs = sym_src(z, g.mir.z0, g.mir.nz);
+    const float2 *spl = src + (int64_t)zs * g.plane;
+    float2 *dpl = dst + (int64_t)z * g.plane;
+    const int lo = g.mir.y0 * TWc, hi = (g.mir.y0 + g.mir.ny) * TWc;
+    auto elem = [&](int i) {
+        const int y = i >> 1, y0c = y & ~(CH - 1);
+        const int rows_c = min(CH, YP - y0c);
+        return ((y0c * g.nT + (y - y0c)) << 2) + ((kt * rows_c) << 2) + ((i & 1) << 1);
+    };
+    float4 *l4 = (float4 *)lds_yms;
+    constexpr int kU = M3D_KU_Y;
+    for (int i0 = lo / 2 + tid; i0 < hi / 2; i0 += NT_ * kU) {
+        float4 v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) v[u] = *(const float4 *)(spl + elem(min(i0 + u * NT_, hi / 2 - 1)));
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (i0 + u * NT_ < hi / 2) l4[i0 + u * NT_] = v[u];
+    }
+    __syncthreads();
+    // rows outside the core: copies of the core rows they mirror (single reflection when the pad is no deeper than
+    // the core, which the host checks before choosing this kernel)
+    const int y_hi = g.mir.y0 + g.mir.ny;
+    for (int i = tid; i < n / 2; i += NT_) {
+        const int y = i >> 1;
+        if (y >= g.mir.y0 && y < y_hi) continue;
+        const int ys = y < g.mir.y0 ? 2 * g.mir.y0 - 1 - y : 2 * y_hi - 1 - y;
+        l4[i] = l4[(ys << 1) + (i & 1)];
+    }
+    __syncthreads();
+    y_stage_static<R0, false, YP, YP, TWc, NT_>(lds_yms, tw, tid);
+    __syncthreads();
+    y_stage_static<R1, false, YP, YP / R0, TWc, NT_>(lds_yms, tw, tid);
+    __syncthreads();
+    y_stage_static<R2, false, YP, YP / (R0 * R1), TWc, NT_>(lds_yms, tw, tid);
+    __syncthreads();
+    if constexpr (R3 > 1) {
+        y_stage_static<R3, false, YP, YP / (R0 * R1 * R2), TWc, NT_>(lds_yms, tw, tid);
+        __syncthreads();
+    }
+    for (int i = tid; i < n / 2; i += NT_) *(float4 *)(dpl + elem(i)) = l4[i];
+}
+
 // Y forward pass of a volume given by its core rows only (symmetric extension along y and z): plane z is
 // built from the rows of core plane sym_src(z) - X transforms of mirrored rows are copies, so the X pass
 // only transforms the core.  Out of place (several planes read the same core plane).
@@ -1312,7 +1364,9 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
 //   z = l + L m, k = k1 + 16 k2:  W_N^(z k) = W_16^(m k1) * W_N^(l k1) * W_L^(l k2).
 // Spectra never leave the kernel, so only the OTF's plane order matters: natural (plane k holds frequency k), written
 // by this kernel's own mode -1.
-template <int L, int P>
+// ZM: what lies outside the input's planes - 0 zero, 1 symmetric extension (general), 2 symmetric extension with one
+// reflection (pad no deeper than the core).  OUTF: every plane of the output is stored (no per-plane test).
+template <int L, int P, int ZM = 1, bool OUTF = false>
 __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__restrict__ spec, const float2 *__restrict__ otf,
                                                        ConvGeo g, const float2 *__restrict__ tw, int mode, float scale)
 {
@@ -1343,11 +1397,12 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
         const bool inside = z >= g.in.z0 && z < zin_hi;
         // outside the input's planes: zero, or (zmirror) the plane it mirrors - the same data again, never zero
         // zmirror == 2: the pad on either side is no deeper than the core, one reflection and no modulo
-        const int zs = inside ? z
-                       : (g.zmirror == 2 ? (z < g.in.z0 ? 2 * g.in.z0 - 1 - z : 2 * zin_hi - 1 - z)
-                                         : (g.zmirror ? sym_src(z, g.in.z0, g.in.nz) : g.in.z0));
+        int zs;
+        if constexpr (ZM == 2) zs = z < g.in.z0 ? 2 * g.in.z0 - 1 - z : (z >= zin_hi ? 2 * zin_hi - 1 - z : z);
+        else if constexpr (ZM == 1) zs = inside ? z : sym_src(z, g.in.z0, g.in.nz);
+        else zs = inside ? z : g.in.z0;
         v[m] = col[(int64_t)zs * g.plane];
-        if (!live || !(inside || g.zmirror)) v[m] = make_float2(0.f, 0.f);
+        if (!live || !(inside || ZM != 0)) v[m] = make_float2(0.f, 0.f);
     }
     float2 w[16];  // W_N^(l k1), l k1 < N: powers 1, 2, 4, 8 from the table, the rest by products
     w[1] = tw[l];
@@ -1424,7 +1479,7 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
         const int z = l + L * m;
-        if (live && z >= g.out.z0 && z < g.out.z0 + g.out.nz) col[(int64_t)z * g.plane] = v[m];
+        if (live && (OUTF || (z >= g.out.z0 && z < g.out.z0 + g.out.nz))) col[(int64_t)z * g.plane] = v[m];
     }
 }
 
@@ -1655,6 +1710,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 2>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<1>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
@@ -1691,8 +1747,18 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
     if (p->zreg) {
         static const int zp = [] { const char *e = getenv("M3D_FFT_ZREG_P"); return e && atoi(e) == 16 ? 16 : 32; }();  // 256-byte segments: 4 % faster
         const unsigned nb = (unsigned)((p->plane + zp - 1) / zp);
-#define M3D_LAUNCH_ZREG(LL, PP) \
-    hipLaunchKernelGGL((k_z_conv_reg<LL, PP>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale)
+        const bool outf = g.out.z0 == 0 && g.out.nz == p->Zp;
+#define M3D_LAUNCH_ZREG(LL, PP)                                                                                       \
+    do {                                                                                                              \
+        if (g.zmirror == 2 && !outf)                                                                                  \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 2, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale); \
+        else if (g.zmirror)                                                                                           \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 1, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale); \
+        else if (outf)                                                                                                \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, true>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale);  \
+        else                                                                                                          \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale); \
+    } while (0)
         if (zp == 32) {
             switch (p->zreg) {
             case 2: M3D_LAUNCH_ZREG(2, 32); break;
@@ -1763,7 +1829,11 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
         launch_x_forward(p, src, spec, g, groups, st);
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
-        if (p->rset_y)
+        const bool one_reflection = g.mir.y0 <= g.mir.ny && p->Yp - (g.mir.y0 + g.mir.ny) <= g.mir.ny;
+        if (p->ystatic && one_reflection)
+            hipLaunchKernelGGL((k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>), dim3(yplanes * (unsigned)p->nT),
+                               dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);
+        else if (p->rset_y)
             hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
         else
             hipLaunchKernelGGL(k_y_forward_mirror<0>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);

@@ -1,4 +1,4 @@
-// Counter-based Binomial(n, 1/2) photon split: Philox4x32-10 + pop-count.
+// Counter-based Binomial(n, 1/2) photon split: Philox4x32 (kSplitRounds rounds) + pop-count.
 //
 // Replaces cp.random.default_rng(seed).binomial(n, 0.5) of the reference
 // (utils/rlgc.py:564, 619-622).  Stateless, so the split is regenerated wherever it is
@@ -22,12 +22,18 @@ struct U32x4 {
     uint32_t x, y, z, w;
 };
 
-M3D_HD U32x4 philox4x32_10(U32x4 c, uint32_t k0, uint32_t k1)
+// Rounds of the photon split.  Random123 recommends 10 as a safety margin; Philox4x32 passes BigCrush from 7 rounds
+// on (Salmon et al., SC'11, table 2), and the split kernel is bound by exactly these multiplies (profiles/
+// r02_pmc_sq_rlgc_after.json: one vector instruction per four cycles per SIMD, 1.5 G of them per launch).
+constexpr int kSplitRounds = 7;
+
+template <int ROUNDS>
+M3D_HD U32x4 philox4x32(U32x4 c, uint32_t k0, uint32_t k1)
 {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
     const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)M0 * c.x;
         const uint64_t p1 = (uint64_t)M1 * c.z;
         U32x4 n;
@@ -41,6 +47,8 @@ M3D_HD U32x4 philox4x32_10(U32x4 c, uint32_t k0, uint32_t k1)
     }
     return c;
 }
+
+M3D_HD U32x4 philox4x32_10(U32x4 c, uint32_t k0, uint32_t k1) { return philox4x32<10>(c, k0, k1); }  // Random123 KAT form
 
 M3D_HD int popc32(uint32_t v)
 {
@@ -65,7 +73,7 @@ M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, ui
     int64_t rem = (int64_t)n;
     while (rem > 0) {
         U32x4 c = {(uint32_t)voxel, (uint32_t)(voxel >> 32), iteration, chunk};
-        const U32x4 r = philox4x32_10(c, k0, k1);
+        const U32x4 r = philox4x32<kSplitRounds>(c, k0, k1);
         if (rem >= 128) {
             acc += popc32(r.x) + popc32(r.y) + popc32(r.z) + popc32(r.w);
         } else {

@@ -7,7 +7,7 @@ The reference draws the RLGC 50:50 split with
 a cuRAND stream nothing else can reproduce.  The MI355X build replaces it by a
 stateless sampler that needs no stored split array: for voxel ``v`` at
 iteration ``it`` the split is the pop-count of ``n`` fresh random bits taken
-from Philox4x32-10 blocks with
+from Philox4x32 blocks (``SPLIT_ROUNDS`` = 7 rounds) with
 
     key     = (seed & 0xffffffff, seed >> 32)
     counter = (v & 0xffffffff, v >> 32, it, chunk)      chunk = 0, 1, ...
@@ -28,15 +28,18 @@ _W1 = 0xBB67AE85
 _MASK32 = np.uint64(0xFFFFFFFF)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0: int, k1: int):
-    """Philox4x32 with 10 rounds on uint32 counter arrays (Random123 definition)."""
+SPLIT_ROUNDS = 7  # = kSplitRounds of csrc/m3d_philox.h (BigCrush-clean from 7 rounds on; 10 is Random123's margin)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0: int, k1: int, rounds: int = 10):
+    """Philox4x32 on uint32 counter arrays (Random123 definition; 10 rounds = the published known-answer form)."""
     c0 = np.asarray(c0, dtype=np.uint64)
     c1 = np.asarray(c1, dtype=np.uint64)
     c2 = np.asarray(c2, dtype=np.uint64)
     c3 = np.asarray(c3, dtype=np.uint64)
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(int(rounds)):
         p0 = _M0 * c0
         p1 = _M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
@@ -84,6 +87,7 @@ def binomial_half(n: np.ndarray, voxel_index: np.ndarray, iteration: int, seed: 
             np.full(sel.shape, chunk, dtype=np.uint64),
             k0,
             k1,
+            rounds=SPLIT_ROUNDS,
         )
         rem = remaining[sel]
         acc = np.zeros(sel.shape, dtype=np.int64)
