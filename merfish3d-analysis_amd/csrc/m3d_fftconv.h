@@ -56,12 +56,16 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
 //       red[0] / red[1] <- min / max of HT1 + HT2 as ordered keys (float_key below)
 //   kUpdate (filter_update rlgc.py:23-31, :682-694, core only): c = result, old = a;
 //       o1 <- c < 0 ? old : old * b; red64[0] += (c >= 0); red[2] <- max o1 (key); red[3] <- max |o1 - old| (bits)
+// The epilogues' reductions end in atomics.  A single record serialises them at one address (~12 ns each, 280 k
+// workgroups: the whole kernel); workgroups spread over kRedSlots records on separate 128-byte lines instead, and
+// the reader folds the records.
+constexpr int kRedSlots = 128, kRedStride = 32;
 struct ConvEpilogue {
     enum Kind { kNone = 0, kConsensus = 1, kUpdate = 2 };
     int kind;
     const float *a, *b;
     float *o1, *o2;
-    unsigned int *red;  // 16-byte aligned, >= 4 words
+    unsigned int *red;  // kRedSlots records of 4 words, kRedStride words apart (128-byte aligned)
     ConvBox core;
 };
 // order-preserving map float -> uint32 (atomicMin / atomicMax on floats of either sign)
@@ -92,6 +96,11 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
 // X pass gathers through the index map instead of reading a materialised pad region.  With a second
 // scratch spectrum `spec_alt` only the box's own rows are transformed along x (mirrored rows have the
 // same transform) and the Y pass assembles every plane from the core plane it mirrors.
+
+// fftconv_to_rows for two inputs that take the same transfer function (the two HTratio convolutions of an RLGC
+// iteration): the Z pass of both runs as one launch that reads each OTF line from HBM once.
+int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *src2, const float2 *otf, int mode,
+                         float2 *spec1, float2 *spec2, void *stream, EventLog *log, const ConvBox *in_box);
 
 // fft_conv without its X inverse pass: afterwards `spec` holds the half spectrum along x of every
 // (z, y) row of the result (rows of `out_box` only).

@@ -68,11 +68,18 @@ struct FftConvPlan {
     int zreg;  // Zp / 16 when the register variant of the Z pass applies (Zp = 32, 64, 128, 256), else 0
     int xreg;  // X passes with register edge stages (radix list 9 ... 9, Xp / 9 <= 254, 256 threads)
     int lch;   // log2 of the rows per y chunk of the spectrum layout
+    int xcdpair;
     int ystatic;  // the Y pass runs its static-geometry build
     int xstatic;  // the register-edge X passes run their static-geometry builds (NS = 2187)
 };
 
 }  // namespace m3d
+
+// this workgroup's reduction record (ConvEpilogue::red, m3d_fftconv.h)
+__device__ __forceinline__ unsigned int *red_slot(unsigned int *red)
+{
+    return red + (blockIdx.x % (unsigned)m3d::kRedSlots) * m3d::kRedStride;
+}
 
 namespace {
 
@@ -82,6 +89,7 @@ struct ConvGeo {
     int GX, GY, GZ;    // transforms one thread carries through a butterfly of each pass
     int lDR;           // log2 of the rows one block of the dual X inverse pass handles
     int lCH;           // log2 of the rows per y chunk of the spectrum layout (see spec_index)
+    int xcdpair;       // dual X pass: row pairs that share lines go to one XCD
     int64_t plane;
     m3d::ConvBox in, out;  // support of the input / needed part of the output (full by default)
     m3d::ConvBox mir;      // mirror != 0: the input is the symmetric extension of this box
@@ -245,7 +253,7 @@ __device__ __forceinline__ void x_inverse_epilogue(const float2 *lds, const Conv
                     const float c = r ? v.y : v.x;
                     if constexpr (EPI == m3d::ConvEpilogue::kConsensus) {
                         const float un = bv[r][u];
-                        const float h1 = av[r][u] / un, h2 = c / un;
+                        const float h1 = av[r][u] * un, h2 = c * un;  // un = 1 / update_norm
                         ep.o1[row[r] + n] = (h1 - 1.0f) * (h2 - 1.0f);
                         const float hs = h1 + h2;
                         mn = fminf(mn, hs);
@@ -269,17 +277,19 @@ __device__ __forceinline__ void x_inverse_epilogue(const float2 *lds, const Conv
         mn = block_min(mn, smf);
         mx = block_max(mx, smf);
         if (tid == 0) {
-            atomicMin(&ep.red[0], m3d::float_key(mn));
-            atomicMax(&ep.red[1], m3d::float_key(mx));
+            unsigned int *red = red_slot(ep.red);
+            atomicMin(&red[0], m3d::float_key(mn));
+            atomicMax(&red[1], m3d::float_key(mx));
         }
     } else {
         updated = block_sum(updated, smu);
         mx = block_max(mx, smf);
         dmax = block_max(dmax, smf);
         if (tid == 0) {
-            if (updated) atomicAdd((unsigned long long *)ep.red, updated);
-            atomicMax(&ep.red[2], m3d::float_key(mx));
-            atomicMax(&ep.red[3], __float_as_uint(dmax));
+            unsigned int *red = red_slot(ep.red);
+            if (updated) atomicAdd((unsigned long long *)red, updated);
+            atomicMax(&red[2], m3d::float_key(mx));
+            atomicMax(&red[3], __float_as_uint(dmax));
         }
     }
 }
@@ -371,7 +381,7 @@ __device__ __forceinline__ void dual_consensus_epilogue(float2 *lds, const ConvG
                 const int n = n0 + u * nt;
                 if (n >= N) continue;
                 const float2 v = lds[bi * N + n];  // (HTratio1 raw, HTratio2 raw)
-                const float h1 = v.x / un[u], h2 = v.y / un[u];
+                const float h1 = v.x * un[u], h2 = v.y * un[u];  // un = 1 / update_norm
                 const float prod = (h1 - 1.0f) * (h2 - 1.0f);
                 if constexpr (CHAIN) {
                     if (bi == 0)
@@ -391,8 +401,9 @@ __device__ __forceinline__ void dual_consensus_epilogue(float2 *lds, const ConvG
     mn = block_min(mn, smf);
     mx = block_max(mx, smf);
     if (tid == 0) {
-        atomicMin(&ep.red[0], m3d::float_key(mn));
-        atomicMax(&ep.red[1], m3d::float_key(mx));
+        unsigned int *red = red_slot(ep.red);
+        atomicMin(&red[0], m3d::float_key(mn));
+        atomicMax(&red[1], m3d::float_key(mx));
     }
 }
 
@@ -483,6 +494,25 @@ __device__ unsigned long long m3d_stamp_buf[512 * 16];
 #define M3D_STAMP_DECL
 #define M3D_STAMP(i) do { } while (0)
 #define M3D_STAMP_FLUSH do { } while (0)
+#endif
+// -DM3D_STAMPS=1 stamps the forward X pass, =2 the dual inverse
+#if defined(M3D_STAMPS) && M3D_STAMPS == 1
+#define M3D_FSTAMP_DECL M3D_STAMP_DECL
+#define M3D_FSTAMP(i) M3D_STAMP(i)
+#define M3D_FSTAMP_FLUSH M3D_STAMP_FLUSH
+#else
+#define M3D_FSTAMP_DECL
+#define M3D_FSTAMP(i) do { } while (0)
+#define M3D_FSTAMP_FLUSH do { } while (0)
+#endif
+#if defined(M3D_STAMPS) && M3D_STAMPS == 2
+#define M3D_DSTAMP_DECL M3D_STAMP_DECL
+#define M3D_DSTAMP(i) M3D_STAMP(i)
+#define M3D_DSTAMP_FLUSH M3D_STAMP_FLUSH
+#else
+#define M3D_DSTAMP_DECL
+#define M3D_DSTAMP(i) do { } while (0)
+#define M3D_DSTAMP_FLUSH do { } while (0)
 #endif
 
 // ================================================================ X passes with register edge stages
@@ -711,8 +741,8 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
-    M3D_STAMP_DECL
-    M3D_STAMP(0);
+    M3D_FSTAMP_DECL
+    M3D_FSTAMP(0);
     // the pair item of the last stage: its two block positions are requested now, used three barriers later
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     const bool pair_live = tid < nb * I;
@@ -753,7 +783,7 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
                 const bool vx = g.mirror || (n >= g.in.x0 && n < x_hi);
                 v[q] = make_float2(va && vx ? a[q] : 0.0f, vb && vx ? b[q] : 0.0f);
             }
-            M3D_STAMP(1 + 2 * bi);   // loads of this row pair have landed
+            M3D_FSTAMP(1 + 2 * bi);   // loads of this row pair have landed
 #ifndef M3D_XF_COPYONLY
             dft9<false>(v);
 #endif
@@ -761,15 +791,15 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
             row[0] = v[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) row[S * q] = cmul(v[q], w[q]);
-            M3D_STAMP(2 + 2 * bi);   // first stage done
+            M3D_FSTAMP(2 + 2 * bi);   // first stage done
         }
     }
     __syncthreads();
-    M3D_STAMP(5);
+    M3D_FSTAMP(5);
 #if !defined(M3D_XF_NOMID) && !defined(M3D_XF_COPYONLY)
     middle_forward<RSET, NS>(lds_fr, ax, nb, N, tid, nt, g.GX);
 #endif
-    M3D_STAMP(6);
+    M3D_FSTAMP(6);
     {
         float2 c1[9], c2[9];
         if (pair_live) forward_pair_load(lds_fr + pbi * N, pu1 / 9, pu2 / 9, c1, c2);
@@ -789,12 +819,12 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
                                      ya + 1 >= g.in.y0 && ya + 1 < y_hi);
         }
     }
-    M3D_STAMP(7);
-#ifdef M3D_STAMPS
+    M3D_FSTAMP(7);
+#if defined(M3D_STAMPS) && M3D_STAMPS == 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    M3D_STAMP(8);
-    M3D_STAMP_FLUSH;
+    M3D_FSTAMP(8);
+    M3D_FSTAMP_FLUSH;
 }
 
 // Fused tails run on the registers of the last inverse stage: thread t holds x[t + S q] of both packed rows.
@@ -804,7 +834,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
 {
 #pragma clang fp contract(off)
     extern __shared__ float2 lds_ir[];
-    __shared__ float smf[4];
+    __shared__ float smf[8];
     __shared__ unsigned long long smu[4];
     const ConvGeo g = static_geo<NS>(g_);
     const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
@@ -840,7 +870,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
     __syncthreads();
     middle_inverse<RSET, NS>(lds_ir, ax, nb, N, tid, nt, g.GX);
     float mx = -INFINITY, dmax = 0.0f;
-    unsigned long long updated = 0;
+    unsigned int updated = 0;
     if (tid < S) {
         float2 w[9];
         edge_twiddles(w, ax.tw, tid);
@@ -884,7 +914,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
                         const float old = av[q];
                         const float nw = c < 0.0f ? old : old * bv[q];
                         ep.o1[rowo[r] + n] = nw;
-                        updated += (c >= 0.0f) ? 1ull : 0ull;
+                        updated += (c >= 0.0f) ? 1u : 0u;
                         mx = fmaxf(mx, nw);
                         dmax = fmaxf(dmax, fabsf(nw - old));
                     }
@@ -893,13 +923,24 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
         }
     }
     if constexpr (EPI == m3d::ConvEpilogue::kUpdate) {
-        updated = block_sum(updated, smu);
-        mx = block_max(mx, smf);
-        dmax = block_max(dmax, smf);
+        // one barrier for the three block reductions (the count is below 2^24 per wave: a 32-bit shuffle sum)
+        const unsigned int upw = m3d::wave_sum(updated);
+        mx = m3d::wave_max(mx);
+        dmax = m3d::wave_max(dmax);
+        if ((tid & 63) == 0) {
+            smu[tid >> 6] = upw;
+            smf[tid >> 6] = mx;
+            smf[4 + (tid >> 6)] = dmax;
+        }
+        __syncthreads();
         if (tid == 0) {
-            if (updated) atomicAdd((unsigned long long *)ep.red, updated);
-            atomicMax(&ep.red[2], m3d::float_key(mx));
-            atomicMax(&ep.red[3], __float_as_uint(dmax));
+            unsigned int *red = red_slot(ep.red);
+            const unsigned long long total = smu[0] + smu[1] + smu[2] + smu[3];
+            mx = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
+            dmax = fmaxf(fmaxf(smf[4], smf[5]), fmaxf(smf[6], smf[7]));
+            if (total) atomicAdd((unsigned long long *)red, total);
+            atomicMax(&red[2], m3d::float_key(mx));
+            atomicMax(&red[3], __float_as_uint(dmax));
         }
     }
 }
@@ -914,14 +955,24 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
 {
 #pragma clang fp contract(off)
     extern __shared__ float2 lds_dr[];
-    __shared__ float smf[4];
+    __shared__ float smf[8];
     const ConvGeo g = static_geo<NS>(g_);
     const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
     const int N = g.Xp, S = N / 9, I = S / 2 + 1;
     const int groups = (g.Yp + 1) / 2;
-    const int z = blockIdx.x / groups, y0 = (blockIdx.x % groups) * 2;
+    // Two consecutive row pairs share every 128-byte line of the tiled spectra (four rows x 32 bytes).  Workgroups b and
+    // b + 8 land on the same XCD, so inside each group of 16 the item order is permuted to give those two workgroups the
+    // two halves of the same lines: the second one finds them in that XCD's L2 (reads) and completes them there (writes).
+    const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
+    const int item = (g.xcdpair && b < (nblk & ~15)) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
+    const int z = item / groups, y0 = (item % groups) * 2;
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     const bool pair_live = tid < 2 * I;
+#ifdef M3D_XD_EMPTY
+    if (g_.Xp != -12345) return;
+#endif
+    M3D_DSTAMP_DECL
+    M3D_DSTAMP(0);
     int pu1 = 0, pu2 = 0;
     if (pair_live) {
         pu1 = ax.pos[kp] / 9;
@@ -933,24 +984,46 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         float2 Av[9], Bv[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
+#ifdef M3D_XD_NOLOAD
+            Av[i] = make_float2(1.0f + (float)(kp + i) * 1e-3f, 0.25f);
+            Bv[i] = make_float2(0.5f, (float)(kp - i) * 1e-3f);
+#else
             Av[i] = spec1[rbase + off[i]];
             Bv[i] = spec2[rbase + off[i]];
+#endif
         }
+#if defined(M3D_STAMPS) && M3D_STAMPS == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        M3D_DSTAMP(1);
         inverse_pair_merge(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
     }
-    // update_norm of both rows: requested before the middle stages, used after them
+    M3D_DSTAMP(2);
+    __syncthreads();
+    M3D_DSTAMP(3);
+#ifndef M3D_XD_NOMID
+    middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
+#else
+    __syncthreads();
+#endif
+    // 1 / update_norm of both rows.  Requested here, not in front of the middle stages: 18 registers held across
+    // them cost more (spills, 3.23 -> 3.04 ms) than the exposed latency of these coalesced loads
     const bool row1 = y0 + 1 < g.Yp;
     const int64_t r0 = ((int64_t)z * g.Yp + y0) * N, r1 = r0 + (row1 ? N : 0);
     float un0[9], un1[9];
     if (tid < S) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
+#ifdef M3D_XD_NOUN
+            un0[q] = 1.0f + (float)q;
+            un1[q] = 2.0f + (float)q;
+#else
             un0[q] = ep.b[r0 + tid + S * q];
             un1[q] = ep.b[r1 + tid + S * q];
+#endif
         }
     }
-    __syncthreads();
-    middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
+    M3D_DSTAMP(4);
     float mn = INFINITY, mx = -INFINITY;
     if (tid < S) {
         float2 w[9];
@@ -973,13 +1046,17 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             for (int q = 0; q < 9; ++q) {
                 const int n = tid + S * q;
                 const float un = r ? un1[q] : un0[q];
-                const float h1 = v[q].x / un, h2 = v[q].y / un;
+                const float h1 = v[q].x * un, h2 = v[q].y * un;  // un = 1 / update_norm
                 const float prod = (h1 - 1.0f) * (h2 - 1.0f);
                 if (live) {
                     const float hs = h1 + h2;
                     mn = fminf(mn, hs);
                     mx = fmaxf(mx, hs);
+#ifdef M3D_XD_NOUN
+                    if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx && hs == 1.2345e30f) ep.o2[rr + n] = hs;
+#else
                     if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[rr + n] = hs;
+#endif
                     if constexpr (!CHAIN) ep.o1[rr + n] = prod;
                 }
                 if (r == 0) pk[q] = make_float2(prod, 0.0f);
@@ -998,21 +1075,47 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
         }
     }
-    mn = block_min(mn, smf);
-    mx = block_max(mx, smf);
-    if (tid == 0) {
-        atomicMin(&ep.red[0], m3d::float_key(mn));
-        atomicMax(&ep.red[1], m3d::float_key(mx));
+    M3D_DSTAMP(5);
+    // per-wave extrema ride the barrier the chained forward needs anyway
+    mn = m3d::wave_min(mn);
+    mx = m3d::wave_max(mx);
+    if ((tid & 63) == 0) {
+        smf[tid >> 6] = mn;
+        smf[4 + (tid >> 6)] = mx;
     }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned int *red = red_slot(ep.red);
+        mn = fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3]));
+        mx = fmaxf(fmaxf(smf[4], smf[5]), fmaxf(smf[6], smf[7]));
+#ifdef M3D_XD_NOATOM
+        if (mn == 1.2345e30f)
+#endif
+        {
+            atomicMin(&red[0], m3d::float_key(mn));
+            atomicMax(&red[1], m3d::float_key(mx));
+        }
+    }
+    M3D_DSTAMP(6);
     if constexpr (CHAIN) {
-        __syncthreads();
+#ifndef M3D_XD_NOMID
         middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
+#else
+        __syncthreads();
+#endif
+        M3D_DSTAMP(7);
         if (tid < I) {
             float2 c1[9], c2[9];
             forward_pair_load(lds_dr, pu1, pu2, c1, c2);
             forward_pair_emit<false>(c1, c2, g, S, kp, spec1, (int64_t)z * g.plane, y0, true, row1);
         }
     }
+    M3D_DSTAMP(8);
+#if defined(M3D_STAMPS) && M3D_STAMPS == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    M3D_DSTAMP(9);
+    M3D_DSTAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------- Y pass (in place)
@@ -1368,7 +1471,8 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
 // reflection (pad no deeper than the core).  OUTF: every plane of the output is stored (no per-plane test).
 template <int L, int P, int ZM = 1, bool OUTF = false>
 __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__restrict__ spec, const float2 *__restrict__ otf,
-                                                       ConvGeo g, const float2 *__restrict__ tw, int mode, float scale)
+                                                       ConvGeo g, const float2 *__restrict__ tw, int mode, float scale,
+                                                       float2 *__restrict__ spec_b = nullptr)
 {
     constexpr int N = 16 * L, LP = P == 32 ? 5 : 4;
     static_assert(P == 16 || P == 32, "16 or 32 columns per block");
@@ -1376,7 +1480,17 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
     constexpr int NBF = 16 / L;    // (k1, column) groups per thread in the cross-thread step
     __shared__ float2 ex[16 * KS];
     const int tid = threadIdx.x, p = tid & (P - 1), l = tid >> LP;
-    const int64_t p0 = (int64_t)blockIdx.x * P;
+    // spec_b: two spectra take the same transfer function.  Workgroups b and b + 8 run on the same XCD one after the
+    // other, so inside each group of 16 the first eight take eight column tiles of `spec` and the second eight the same
+    // tiles of `spec_b`: the second reader of every OTF line finds it in that XCD's L2 instead of in HBM.
+    int64_t tile = blockIdx.x;
+    if (spec_b) {
+        const int b = (int)blockIdx.x;
+        tile = (int64_t)(b >> 4) * 8 + (b & 7);
+        if (tile * P >= g.plane) return;
+        if (b & 8) spec = spec_b;
+    }
+    const int64_t p0 = tile * P;
     const bool live = p0 + p < g.plane;
     const int64_t pc = live ? p0 + p : g.plane - 1;
     float2 *col = spec + pc;
@@ -1565,6 +1679,7 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
     g.GZ = p->gz;
     g.lDR = __builtin_ctz((unsigned)p->dual_rows);
     g.lCH = p->lch;
+    g.xcdpair = p->xcdpair;
     return g;
 }
 
@@ -1625,6 +1740,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->dual_rows = knob("M3D_FFT_DUAL_ROWS", 2);
     p->dual_threads = knob("M3D_FFT_DUAL_T", 256);
     p->ythreads = knob("M3D_FFT_YT", 768);
+    p->xcdpair = knob("M3D_FFT_XCDPAIR", 1) ? 1 : 0;
     {   // rows per y chunk of the spectrum layout: a power of two >= 4 (whole X blocks); >= Yp = plain tiled layout
         int ch = std::max(4, knob("M3D_FFT_CH", 128));
         p->lch = 31 - __builtin_clz((unsigned)ch);
@@ -1741,23 +1857,29 @@ static int row_groups(const FftConvPlan *p, const m3d::ConvBox &b)
 
 // One Z pass (mode -1: forward only, OTF construction) with the kernel family the plan uses throughout.
 static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, const ConvGeo &g, int mode, float scale,
-                     hipStream_t st)
+                     hipStream_t st, float2 *spec_b = nullptr)
 {
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
+    if (!p->zreg && spec_b) {  // the LDS variant has no paired form
+        launch_z(p, spec, otf, g, mode, scale, st);
+        launch_z(p, spec_b, otf, g, mode, scale, st);
+        return;
+    }
     if (p->zreg) {
         static const int zp = [] { const char *e = getenv("M3D_FFT_ZREG_P"); return e && atoi(e) == 16 ? 16 : 32; }();  // 256-byte segments: 4 % faster
-        const unsigned nb = (unsigned)((p->plane + zp - 1) / zp);
+        const unsigned ntile = (unsigned)((p->plane + zp - 1) / zp);
+        const unsigned nb = spec_b ? ((ntile + 7) / 8) * 16 : ntile;  // pairs of eight tiles (see k_z_conv_reg)
         const bool outf = g.out.z0 == 0 && g.out.nz == p->Zp;
 #define M3D_LAUNCH_ZREG(LL, PP)                                                                                       \
     do {                                                                                                              \
         if (g.zmirror == 2 && !outf)                                                                                  \
-            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 2, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale); \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 2, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
         else if (g.zmirror)                                                                                           \
-            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 1, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale); \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 1, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
         else if (outf)                                                                                                \
-            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, true>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale);  \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, true>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b);  \
         else                                                                                                          \
-            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale); \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
     } while (0)
         if (zp == 32) {
             switch (p->zreg) {
@@ -1889,6 +2011,27 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     launch_z(p, spec, otf, g, mode, scale, st);
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
     launch_y_pass<true>(p, spec, g, g.out.nz, st);
+    if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *src2, const float2 *otf, int mode,
+                         float2 *spec1, float2 *spec2, void *stream, EventLog *log, const ConvBox *in_box)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!src1 || !src2 || !spec1 || !spec2 || spec1 == spec2 || !box_ok(p, in_box)) return M3D_ERR_INVALID_ARG;
+    int rc = launch_forward_xy(p, src1, spec1, st, log, in_box, nullptr, nullptr);
+    if (!rc) rc = launch_forward_xy(p, src2, spec2, st, log, in_box, nullptr, nullptr);
+    if (rc) return rc;
+    if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
+    ConvGeo g = geo_of(p, in_box, nullptr);
+    g.zmirror = 0;
+    const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
+    launch_z(p, spec1, otf, g, mode, scale, st, spec2);
+    if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
+    launch_y_pass<true>(p, spec1, g, g.out.nz, st);
+    launch_y_pass<true>(p, spec2, g, g.out.nz, st);
     if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;

@@ -149,11 +149,14 @@ __global__ void k_mask(float *__restrict__ dst, Geo g)
     }
 }
 
-__global__ void k_floor(float *__restrict__ p, float floor_v, int64_t n)
+// update_norm is constant over a run and only ever divides: it is kept as its correctly rounded reciprocal, so
+// the per-iteration HT = w / update_norm (rlgc.py:661,671) is one multiply (<= 1 ulp from the quotient, inside
+// the FFT's own rounding).
+__global__ void k_floor_reciprocal(float *__restrict__ p, float floor_v, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = fmaxf(p[i], floor_v);
+        p[i] = rn_div(1.0f, fmaxf(p[i], floor_v));
 }
 
 template <typename T>
@@ -329,8 +332,8 @@ __global__ void k_consensus_in(float *__restrict__ w1, const float *__restrict__
         const int64_t base = r * g.Xp;
         for (int x = threadIdx.x; x < g.Xp; x += 64) {
             const float u = un[base + x];
-            const float h1 = rn_div(w1[base + x], u);
-            const float h2 = rn_div(w2[base + x], u);
+            const float h1 = w1[base + x] * u;  // u = 1 / update_norm
+            const float h2 = w2[base + x] * u;
             prod[base + x] = (h1 - 1.0f) * (h2 - 1.0f);
             const float hs = h1 + h2;
             mn = fminf(mn, hs);
@@ -422,19 +425,39 @@ __device__ __forceinline__ void arm_fused_reductions(unsigned int *cons, unsigne
     upd[2] = m3d::float_key(-INFINITY);   // max of the new estimate
     upd[3] = 0u;                          // max |delta| (non-negative: raw bits order like floats)
 }
+// one thread per record (m3d::kRedSlots of them, m3d_fftconv.h)
 __global__ void k_arm_fused_reductions(unsigned int *cons, unsigned int *upd)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) arm_fused_reductions(cons, upd);
+    const int s = threadIdx.x;
+    if (blockIdx.x == 0 && s < m3d::kRedSlots) arm_fused_reductions(cons + s * m3d::kRedStride, upd + s * m3d::kRedStride);
 }
 __global__ void k_fused_finalize(unsigned int *cons, unsigned int *upd, Status *st)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    st->updated = *(const unsigned long long *)upd;
-    st->recon_max = m3d::key_float(upd[2]);
-    st->max_abs_delta = __uint_as_float(upd[3]);
-    st->ht_min = m3d::key_float(cons[0]);
-    st->ht_max = m3d::key_float(cons[1]);
-    arm_fused_reductions(cons, upd);
+    __shared__ unsigned long long smu[4];
+    __shared__ float smf[4];
+    if (blockIdx.x != 0) return;
+    const int s = threadIdx.x;
+    const bool live = s < m3d::kRedSlots;
+    unsigned int *c = cons + (live ? s : 0) * m3d::kRedStride, *u = upd + (live ? s : 0) * m3d::kRedStride;
+    unsigned long long updated = live ? *(const unsigned long long *)u : 0ull;
+    float recon_max = live ? m3d::key_float(u[2]) : -INFINITY;
+    float delta = live ? __uint_as_float(u[3]) : 0.0f;
+    float ht_min = live ? m3d::key_float(c[0]) : INFINITY;
+    float ht_max = live ? m3d::key_float(c[1]) : -INFINITY;
+    __syncthreads();
+    if (live) arm_fused_reductions(c, u);
+    updated = block_sum(updated, smu);
+    recon_max = block_max(recon_max, smf);
+    delta = block_max(delta, smf);
+    ht_min = block_min(ht_min, smf);
+    ht_max = block_max(ht_max, smf);
+    if (s == 0) {
+        st->updated = updated;
+        st->recon_max = recon_max;
+        st->max_abs_delta = delta;
+        st->ht_min = ht_min;
+        st->ht_max = ht_max;
+    }
 }
 
 // order-independent 64-bit fingerprint of the PSF values (position-salted splitmix64 of the bit patterns)
@@ -866,7 +889,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         hipLaunchKernelGGL(k_mask, dim3(g_pad), rb, 0, st, hu, g);
         M3D_KERNEL_CHECK();
         if ((rc = conv(hu, 1, un, kInCore))) return rc;
-        hipLaunchKernelGGL(k_floor, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, un, 1e-6f, g.Np);
+        hipLaunchKernelGGL(k_floor_reciprocal, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, un, 1e-6f, g.Np);
         M3D_KERNEL_CHECK();
         p->setup_workspace = workspace;
         p->setup_psf_hash = psf_hash;
@@ -886,7 +909,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     hipLaunchKernelGGL(k_fill_from, dim3(grid_for(g.Np)), dim3(kBlock), 0, st, recon_cur,
                        &dstat->mean, g.Np);
     M3D_KERNEL_CHECK();
-    if (fused_tail) hipLaunchKernelGGL(k_arm_fused_reductions, dim3(1), dim3(64), 0, st, cons_red, upd_red);
+    if (fused_tail) hipLaunchKernelGGL(k_arm_fused_reductions, dim3(1), dim3(kBlock), 0, st, cons_red, upd_red);
     // ratio volumes: pad region stays zero for the whole run (only the core is rewritten)
     M3D_HIP_CHECK(hipMemsetAsync(r1, 0, sizeof(float) * (size_t)g.Np, st));
     M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
@@ -919,8 +942,13 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             float2 *cbuf2 = (float2 *)w2;  // w2 itself is never materialised on this path
             const m3d::ConvBox *in = &core;
             elog.convolutions += 2;
-            if ((rc2 = m3d::fftconv_to_rows(p->fc, r1, otf, 1, cbuf, st, &elog, in, nullptr, nullptr))) return rc2;
-            if ((rc2 = m3d::fftconv_to_rows(p->fc, r2, otf, 1, cbuf2, st, &elog, in, nullptr, nullptr))) return rc2;
+            static const bool zpair = !(getenv("M3D_RLGC_NO_ZPAIR") && atoi(getenv("M3D_RLGC_NO_ZPAIR")));
+            if (zpair) {
+                if ((rc2 = m3d::fftconv_to_rows_pair(p->fc, r1, r2, otf, 1, cbuf, cbuf2, st, &elog, in))) return rc2;
+            } else {
+                if ((rc2 = m3d::fftconv_to_rows(p->fc, r1, otf, 1, cbuf, st, &elog, in, nullptr, nullptr))) return rc2;
+                if ((rc2 = m3d::fftconv_to_rows(p->fc, r2, otf, 1, cbuf2, st, &elog, in, nullptr, nullptr))) return rc2;
+            }
             // ... and the consensus input goes straight into the X forward transform of its own convolution
             const bool chain = !(getenv("M3D_RLGC_NO_CHAIN") && atoi(getenv("M3D_RLGC_NO_CHAIN")));
             const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, nullptr, un, hu, w1, cons_red, core};
@@ -928,7 +956,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             const m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr,
                                           upd_red, core};
             if ((rc2 = conv(chain ? nullptr : hu, 2, w2, kOutCore, &e2))) return rc2;
-            hipLaunchKernelGGL(k_fused_finalize, dim3(1), dim3(64), 0, st, cons_red, upd_red, dstat);
+            hipLaunchKernelGGL(k_fused_finalize, dim3(1), dim3(kBlock), 0, st, cons_red, upd_red, dstat);
             M3D_KERNEL_CHECK();
             return M3D_OK;
         }
