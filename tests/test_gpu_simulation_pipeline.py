@@ -14,8 +14,13 @@ from scipy.ndimage import gaussian_filter
 from conftest import pkg
 
 pytestmark = pytest.mark.gpu
-SHIFTS = [(0, 0, 0), (0.6, 2.4, -3.1), (-0.4, -1.7, 2.2), (0.3, 3.6, 0.8), (0.0, -2.9, -1.4), (0.7, 1.2, 3.3),
-          (-0.5, -3.8, -0.6), (0.2, 0.9, -2.7)]
+# Lateral shifts of 5-9 px on purpose.  phase_cross_correlation(disambiguate=True) - the reference's call
+# (multiview_registration.py:266-271), restated faithfully - decides between a shift and its wrapped twins by the
+# correlation coefficient over the overlap tiles, and accepts tiles of as few as three pixels: with shifts that round
+# to 1-4 px the corner tile holds 3-12 samples whose coefficient exceeds the true tile's 0.8-0.9 about one time in
+# ten (that did flip one round of an earlier, smaller shift set by 128 px).  At 30-80 samples it cannot.
+SHIFTS = [(0, 0, 0), (0.6, 6.4, -7.1), (-0.4, -7.7, 6.2), (0.3, 8.6, 5.8), (0.0, -6.9, -8.4), (0.7, 5.2, 9.3),
+          (-0.5, -8.8, -5.6), (0.2, 6.9, -7.7)]
 
 
 def _predictor(image):
@@ -59,6 +64,7 @@ def test_simulation_f1_sofima_not_below_affine(tmp_path):
         res = sim.calculate_F1(store, gt, search_radius=1.0)
         scores[mode] = res
         print(f"\\n{mode}: {res}")
+        print(np.array2string(shifts_found[mode], precision=2, suppress_small=True))
     # registration recovered the planted round shifts (pull = + shift) to within the smooth warp that rides on them
     # (amplitude 1.2 px: the rigid estimate locks onto the dominant displacement, the residual is SOFIMA's job)
     np.testing.assert_allclose(shifts_found["affine"], np.asarray(SHIFTS), atol=1.2 + 0.35)
