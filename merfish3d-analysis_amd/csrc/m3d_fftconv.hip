@@ -1474,8 +1474,8 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
                                                        ConvGeo g, const float2 *__restrict__ tw, int mode, float scale,
                                                        float2 *__restrict__ spec_b = nullptr)
 {
-    constexpr int N = 16 * L, LP = P == 32 ? 5 : 4;
-    static_assert(P == 16 || P == 32, "16 or 32 columns per block");
+    constexpr int N = 16 * L, LP = P == 64 ? 6 : (P == 32 ? 5 : 4);
+    static_assert(P == 16 || P == 32 || P == 64, "16, 32 or 64 columns per block");
     constexpr int KS = L * P + P;  // stride between k1 slabs, padded by one row of columns: conflict-free both ways
     constexpr int NBF = 16 / L;    // (k1, column) groups per thread in the cross-thread step
     __shared__ float2 ex[16 * KS];
@@ -1866,7 +1866,10 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
         return;
     }
     if (p->zreg) {
-        static const int zp = [] { const char *e = getenv("M3D_FFT_ZREG_P"); return e && atoi(e) == 16 ? 16 : 32; }();  // 256-byte segments: 4 % faster
+        static const int zp_env = [] { const char *e = getenv("M3D_FFT_ZREG_P"); return e ? atoi(e) : 0; }();  // 256-byte segments: 4 % faster
+        // columns per block: 512-byte segments (64 columns, 512 threads) are 2-7 % faster than 256-byte ones where the
+        // exchange buffer still lets two blocks share a CU (Zp = 128); 16 columns only on request
+        const int zp = zp_env == 16 ? 16 : (zp_env == 32 ? 32 : (p->zreg == 8 ? 64 : 32));
         const unsigned ntile = (unsigned)((p->plane + zp - 1) / zp);
         const unsigned nb = spec_b ? ((ntile + 7) / 8) * 16 : ntile;  // pairs of eight tiles (see k_z_conv_reg)
         const bool outf = g.out.z0 == 0 && g.out.nz == p->Zp;
@@ -1881,7 +1884,9 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
         else                                                                                                          \
             hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
     } while (0)
-        if (zp == 32) {
+        if (zp == 64 && p->zreg == 8) {
+            M3D_LAUNCH_ZREG(8, 64);
+        } else if (zp >= 32) {
             switch (p->zreg) {
             case 2: M3D_LAUNCH_ZREG(2, 32); break;
             case 4: M3D_LAUNCH_ZREG(4, 32); break;

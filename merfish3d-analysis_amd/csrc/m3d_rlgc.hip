@@ -260,15 +260,18 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
                 B1 += b1;
                 B2 += b2;
                 if (a > 0.0f) {
-                    const float la = __logf(a);
-                    Tim += a * (la - __logf(bim));
-                    T1 += a * (la - __logf(b1));
-                    T2 += a * (la - __logf(b2));
+                    // base-2 logarithms straight from v_log_f32 (arguments >= 1e-4: no denormal path); the sums are
+                    // scaled by ln 2 once, in double, when the block's partials are written
+                    const float la = __builtin_amdgcn_logf(a);
+                    Tim += a * (la - __builtin_amdgcn_logf(bim));
+                    T1 += a * (la - __builtin_amdgcn_logf(b1));
+                    T2 += a * (la - __builtin_amdgcn_logf(b2));
                 }
-                // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668
-                const float den = 0.5f * (h + 1e-12f);
-                r1[prow + x] = rn_div(s1, den);
-                r2[prow + x] = rn_div(s2, den);
+                // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668: one correctly rounded reciprocal serves both
+                // quotients (<= 1 ulp from the two divisions, below the rounding of the transforms that consume them)
+                const float inv = rn_div(1.0f, 0.5f * (h + 1e-12f));
+                r1[prow + x] = s1 * inv;
+                r2[prow + x] = s2 * inv;
             }
         }
         // fold the row's float32 partials into double every row (bounded error growth)
@@ -284,7 +287,8 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
     dT1 = block_sum(dT1, sm);
     dT2 = block_sum(dT2, sm);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        KlPartial p = {dA, dBim, dB1, dB2, dTim, dT1, dT2};
+        const double ln2 = 0.69314718055994530942;
+        KlPartial p = {dA, dBim, dB1, dB2, dTim * ln2, dT1 * ln2, dT2 * ln2};
         partial[blockIdx.x] = p;
     }
 }
