@@ -13,7 +13,7 @@ import json
 import re
 import sys
 
-CONV = ("k_x_forward", "k_y_pass<false", "k_z_conv", "k_y_pass<true", "k_x_inverse")
+CONV = ("k_x_forward", "k_y_pass", "k_y_forward_mirror", "k_z_conv", "k_x_inverse")  # name prefixes of the passes
 
 
 def rows(path):
@@ -60,7 +60,9 @@ def main():
         }
     # one Z pass per convolution (the two ratio convolutions share their X inverse pass); the OTF's
     # forward-only Z pass of the first call is counted too
-    n_conv = sum(len(v) for k, v in fetch.items() if k.startswith("k_z_conv"))
+    # (round 2: the two ratio convolutions share one paired Z launch - the all-planes variant "..., 0, true>" - which
+    # therefore counts twice)
+    n_conv = sum(len(v) * (2 if k.endswith("0, true>") else 1) for k, v in fetch.items() if k.startswith("k_z_conv"))
     total = 0.0
     for k, v in kernels.items():
         if k.startswith(CONV):
