@@ -32,7 +32,7 @@ mem = DS.InMemoryDataStore(**kw)
 disk = DS.ZarrImageDataStore(root, device="cuda:0", **kw)
 n_em = int(80_000 * np.prod(shape) / (64 * 2048 * 2048))
 for t in range(n_tiles):
-    ro, pr, _ = bench.make_tile(shape, bits, n_em, 10 + t, dev, kernels)
+    ro, pr, _, _ = bench.make_tile(shape, bits, n_em, 10 + t, dev, kernels)
     for b in range(n_bits):
         for store in (mem, disk):
             store.set_corrected_image(ro[b], tile=t, bit=b)

@@ -21,7 +21,7 @@ shape, n_bits = (64, 2048, 2048), 22
 dev = torch.device("cuda:0")
 codebook = bench.hw4_codebook(n_bits)
 bits = codebook.iloc[:, 1:].to_numpy(dtype=np.int64)
-ro, pr, _ = bench.make_tile(shape, bits, 80_000, 1, dev, kernels)
+ro, pr, _, _ = bench.make_tile(shape, bits, 80_000, 1, dev, kernels)
 store = DS.InMemoryDataStore(num_tiles=1, num_rounds=1, num_bits=n_bits, codebook=codebook)
 for b in range(n_bits):
     store.set_corrected_image(ro[b], tile=0, bit=b)

@@ -53,3 +53,21 @@ def test_world_size_must_match_gpus():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: no file of the package names it, and bench.py imports it in cpu_baseline only."""
+    import ast
+
+    pkg_dir = ROOT / "merfish3d-analysis_amd"
+    for path in list(pkg_dir.rglob("*.py")) + [ROOT / "merfish3d_analysis_amd.py"]:
+        assert "oracle" not in path.read_text().lower(), path
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    importers = set()
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+        for node in (fn.body if isinstance(fn, ast.Module) else ast.walk(fn)):
+            if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                importers.add(getattr(fn, "name", "<module>"))
+            if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                importers.add(getattr(fn, "name", "<module>"))
+    assert importers <= {"cpu_baseline"}, importers
