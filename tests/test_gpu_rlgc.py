@@ -111,9 +111,11 @@ def _phantom(shape, psf_shape, sigma, n_spots, seed):
 
 
 @pytest.mark.parametrize("shape,psf_shape,padded", [((22, 70, 72), (9, 9, 9), (32, 81, 81)),
-                                                    ((52, 70, 150), (11, 9, 9), (64, 81, 162))])
+                                                    ((52, 70, 150), (11, 9, 9), (64, 81, 162)),
+                                                    ((100, 70, 72), (17, 9, 9), (128, 81, 81))])
 def test_solver_with_register_z_pass_matches_oracle(shape, psf_shape, padded):
-    """Padded Z = 32 / 64: the production Z pass (k_z_conv_reg: 16-point DFTs in registers around one LDS exchange),
+    """Padded Z = 32 / 64 / 128 (the last is the headline configuration's variant: 64 columns per block, the two
+    ratio convolutions in one paired launch): the production Z pass (k_z_conv_reg: 16-point DFTs in registers around one LDS exchange),
     the planes mirrored in LDS, the fused consensus / update tails and the register-edge X passes (81 = 9 * 9,
     162 = 9 * 2 * 9) all inside the solver, against the independent NumPy implementation - same Philox stream."""
     rl = pkg("utils.rlgc")
