@@ -9,16 +9,18 @@
 //                                     so the padded copy of rlgc.py:571-576 is never built
 //   otf        c64 [Zp,Yp,Xp/2+1]     rfftn of the embedded PSF; conj / |.|^2 formed on the
 //                                     fly (rlgc.py:582-584 keeps three arrays)
-//   update_norm, reconA, reconB, hu, r1, r2, w1, w2   f32 [Zp,Yp,Xp]
-//   cbuf       c64 [Zp,Yp,Xp/2+1]     rocFFT out-of-place spectrum scratch
+//   update_norm (kept as 1 / update_norm), reconA, reconB, hu, r1, r2, w1, w2   f32 [Zp,Yp,Xp]
+//   cbuf       c64 [Zp,Yp,Xp/2+1]     spectrum scratch (tiled layout of m3d_fftconv.hip; plain for the rocFFT path)
 //
 // Per iteration (rlgc.py:616-736) the ~40 CuPy elementwise/reduction launches become five
-// fused kernels around four rocFFT convolutions:
+// fused kernels around four FFT convolutions.  This is the unfused form (rocFFT path, or M3D_FFT_PRUNE=0);
+// with the fused FFT engine the consensus / update arithmetic runs inside the X inverse passes (ConvEpilogue,
+// m3d_fftconv.h) and k_consensus_in, k_update, k_boundary are not launched:
 //   conv(recon, otf) -> hu
 //   k_split_ratio : Philox split regenerated in registers, KL partial sums for the three
 //                   divergences, both ratio volumes written (core region only)
 //   conv(r1, otf^*) -> w1 ; conv(r2, otf^*) -> w2
-//   k_consensus_in: HT1, HT2 = w / update_norm; (HT1-1)(HT2-1) -> hu ; HT1+HT2 -> w1 (core)
+//   k_consensus_in: HT1, HT2 = w * (1 / update_norm); (HT1-1)(HT2-1) -> hu ; HT1+HT2 -> w1 (core)
 //   conv(hu, |otf|^2) -> w2
 //   k_update      : gated multiplicative update on the core + stop-test reductions
 //   k_boundary    : symmetric-extension gather into the pad region (the three
