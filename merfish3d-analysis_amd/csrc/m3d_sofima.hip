@@ -636,6 +636,173 @@ int m3d_xcorr_peaks(const void *buf_c64, int32_t count, const int32_t fft_zyx[3]
     return M3D_OK;
 }
 
+// Three offsets per axis whose span fits a three-point window (the configured -0.5, 0, 0.5): all 27 candidates in ONE
+// pass over the patch.  Order-1 interpolation is separable and its weights are the same for every voxel of a patch,
+// so a voxel's 27 samples come from its 3 x 3 x 3 window neighbourhood through three small contractions (x, y, z:
+// 81 fused multiply-adds each) instead of 27 x 8 gathers, and the normalised SSD of :373-399 follows from five running
+// sums per candidate,
+//     score = var_s / sd_s^2 + var_p / sd_p^2 - 2 cov / (sd_s sd_p),    sd = max(sqrt(var), eps),
+// (= mean(((S - mean S) / sd_s - (P - mean P) / sd_p)^2) expanded), accumulated on values shifted by the window mean
+// so that the variances are not differences of large numbers.  Per-thread float partials (40 voxels), wave butterfly in
+// float, the four wave partials and the final arithmetic in double.
+__global__ __launch_bounds__(256) void k_subpixel_refine3(const float *__restrict__ pre, const float *__restrict__ post,
+                                                          RefineArgs A, const int *__restrict__ nodes,
+                                                          const float *__restrict__ vec, float *__restrict__ out)
+{
+    extern __shared__ float win[];  // pre window minus its mean; afterwards the wave partials
+    __shared__ double smd[4];
+    __shared__ float s_m0;
+    __shared__ double s_sum[83];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int pv = A.patch.z * A.patch.y * A.patch.x;
+    const int gz = nodes[3 * n + 0], gy = nodes[3 * n + 1], gx = nodes[3 * n + 2];
+    const float vx = vec[3 * n + 0], vy = vec[3 * n + 1], vz = vec[3 * n + 2];
+    const int sz = gz * A.step.z, sy = gy * A.step.y, sx = gx * A.step.x;
+    const float bz = (float)sz + vz, by = (float)sy + vy, bx = (float)sx + vx;
+    const int rz0 = (int)floorf(bz + A.off_min), ry0 = (int)floorf(by + A.off_min), rx0 = (int)floorf(bx + A.off_min);
+    const int Ry = A.region.y, Rx = A.region.x;
+    const int rv = A.region.z * Ry * Rx;
+
+    // pre window -> LDS (zero outside the image: map_coordinates mode="constant", cval=0), then minus its mean
+    float acc = 0.f;
+    {
+        int ux = tid % Rx, uy = (tid / Rx) % Ry, uz = tid / (Rx * Ry);
+        const int qx = 256 % Rx, qy = (256 / Rx) % Ry, qz = 256 / (Rx * Ry);
+        for (int i = tid; i < rv; i += 256) {
+            const int z = rz0 + uz, y = ry0 + uy, x = rx0 + ux;
+            float v = 0.f;
+            if (z >= 0 && y >= 0 && x >= 0 && z < A.shape.z && y < A.shape.y && x < A.shape.x)
+                v = pre[((int64_t)z * A.shape.y + y) * A.shape.x + x];
+            win[i] = v;
+            acc += v;
+            ux += qx;
+            int c = ux >= Rx ? 1 : 0;
+            ux -= c ? Rx : 0;
+            uy += qy + c;
+            c = uy >= Ry ? 1 : 0;
+            uy -= c ? Ry : 0;
+            uz += qz + c;
+        }
+    }
+    const double wsum = block_sum((double)acc, smd);
+    if (tid == 0) s_m0 = (float)(wsum / (double)rv);
+    __syncthreads();
+    const float m0 = s_m0;
+    for (int i = tid; i < rv; i += 256) win[i] -= m0;
+    __syncthreads();
+
+    // per-axis weights of the three candidates over the three window points (uniform over the block)
+    float wz[3][3], wy[3][3], wx[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float cz = bz + A.off[k], cy = by + A.off[k], cx = bx + A.off[k];
+        const float fz = floorf(cz), fy = floorf(cy), fx = floorf(cx);
+        const float tz = cz - fz, ty = cy - fy, tx = cx - fx;
+        const int lz = (int)fz - rz0, ly = (int)fy - ry0, lx = (int)fx - rx0;  // 0 or 1
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            wz[k][j] = j == lz ? 1.f - tz : (j == lz + 1 ? tz : 0.f);
+            wy[k][j] = j == ly ? 1.f - ty : (j == ly + 1 ? ty : 0.f);
+            wx[k][j] = j == lx ? 1.f - tx : (j == lx + 1 ? tx : 0.f);
+        }
+    }
+
+    float s1[27], s2[27], sp[27], p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 27; ++c) s1[c] = s2[c] = sp[c] = 0.f;
+    {
+        const int px = A.patch.x, py = A.patch.y;
+        int ux = tid % px, uy = (tid / px) % py, uz = tid / (px * py);
+        const int qx = 256 % px, qy = (256 / px) % py, qz = 256 / (px * py);
+        for (int i = tid; i < pv; i += 256) {
+            const int z = sz + uz, y = sy + uy, x = sx + ux;
+            float pval = 0.f;
+            if (z < A.shape.z && y < A.shape.y && x < A.shape.x) pval = post[((int64_t)z * A.shape.y + y) * A.shape.x + x];
+            const float P = pval - m0;
+            p1 += P;
+            p2 += P * P;
+            const float *w0 = win + (uz * Ry + uy) * Rx + ux;
+            float B[3][3][3];  // [window z][candidate y][candidate x]
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float Ar[3][3];  // [window y][candidate x]
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const float *r = w0 + (a * Ry + b) * Rx;
+                    const float c0 = r[0], c1 = r[1], c2 = r[2];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) Ar[b][kx] = c0 * wx[kx][0] + c1 * wx[kx][1] + c2 * wx[kx][2];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        B[a][ky][kx] = Ar[0][kx] * wy[ky][0] + Ar[1][kx] * wy[ky][1] + Ar[2][kx] * wy[ky][2];
+            }
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float S = B[0][ky][kx] * wz[kz][0] + B[1][ky][kx] * wz[kz][1] + B[2][ky][kx] * wz[kz][2];
+                        const int c = (kz * 3 + ky) * 3 + kx;
+                        s1[c] += S;
+                        s2[c] += S * S;
+                        sp[c] += S * P;
+                    }
+            ux += qx;
+            int c = ux >= px ? 1 : 0;
+            ux -= c ? px : 0;
+            uy += qy + c;
+            c = uy >= py ? 1 : 0;
+            uy -= c ? py : 0;
+            uz += qz + c;
+        }
+    }
+    __syncthreads();  // every thread is done with the window: it becomes the wave partials [4][83]
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+        s1[c] = wave_sum(s1[c]);
+        s2[c] = wave_sum(s2[c]);
+        sp[c] = wave_sum(sp[c]);
+    }
+    p1 = wave_sum(p1);
+    p2 = wave_sum(p2);
+    if ((tid & 63) == 0) {
+        float *dst = win + (tid >> 6) * 83;
+#pragma unroll
+        for (int c = 0; c < 27; ++c) {
+            dst[c] = s1[c];
+            dst[27 + c] = s2[c];
+            dst[54 + c] = sp[c];
+        }
+        dst[81] = p1;
+        dst[82] = p2;
+    }
+    __syncthreads();
+    if (tid < 83) s_sum[tid] = (double)win[tid] + (double)win[83 + tid] + (double)win[166 + tid] + (double)win[249 + tid];
+    __syncthreads();
+    if (tid == 0) {
+        const double inv = 1.0 / (double)pv, eps = (double)A.eps;
+        const double mp = s_sum[81] * inv, varp = fmax(s_sum[82] * inv - mp * mp, 0.0), sdp = fmax(sqrt(varp), eps);
+        int best = 0;
+        float best_score = 0.f;
+        for (int c = 0; c < 27; ++c) {
+            const double ms = s_sum[c] * inv, vars = fmax(s_sum[27 + c] * inv - ms * ms, 0.0);
+            const double sds = fmax(sqrt(vars), eps), cov = s_sum[54 + c] * inv - ms * mp;
+            const float score = (float)(vars / (sds * sds) + varp / (sdp * sdp) - 2.0 * cov / (sds * sdp));
+            if (c == 0 || score < best_score) {  // first minimum (argmin)
+                best = c;
+                best_score = score;
+            }
+        }
+        out[3 * n + 0] = vx + A.off[best % 3];
+        out[3 * n + 1] = vy + A.off[(best / 3) % 3];
+        out[3 * n + 2] = vz + A.off[best / 9];
+    }
+}
+
 int m3d_subpixel_refine(const float *pre, const float *post, const int32_t shape_zyx[3],
                         const int32_t patch_zyx[3], const int32_t step_zyx[3], const int32_t *nodes_zyx,
                         const float *vectors_xyz, int32_t n, const float *offsets_host, int32_t n_offsets,
@@ -669,6 +836,18 @@ int m3d_subpixel_refine(const float *pre, const float *post, const int32_t shape
     if (lds_bytes > 160 * 1024 - 2048) {
         set_err("m3d_subpixel_refine", "patch does not fit the 160 KiB LDS of one CU");
         return M3D_ERR_UNSUPPORTED;
+    }
+    // three offsets over a three-point window: the one-pass kernel (window only in LDS: two workgroups per CU)
+    static const bool one_pass_ok = !(getenv("M3D_SUBPIXEL_ONE_PASS") && atoi(getenv("M3D_SUBPIXEL_ONE_PASS")) == 0);
+    const size_t win_bytes = sizeof(float) * (size_t)A.region.z * A.region.y * A.region.x;
+    if (one_pass_ok && n_offsets == 3 && extra == 3 && win_bytes >= sizeof(float) * 4 * 83 &&
+        offsets_host[0] <= offsets_host[1] && offsets_host[1] <= offsets_host[2]) {
+        M3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_subpixel_refine3,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
+        hipLaunchKernelGGL(k_subpixel_refine3, dim3(n), dim3(256), win_bytes, (hipStream_t)stream, pre, post, A,
+                           nodes_zyx, vectors_xyz, out_xyz);
+        M3D_KERNEL_CHECK();
+        return M3D_OK;
     }
     M3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_subpixel_refine,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
