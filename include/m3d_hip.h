@@ -316,6 +316,18 @@ int m3d_xcorr_peaks(const void *buf_c64, int32_t count, const int32_t fft_zyx[3]
                     const int32_t patch_zyx[3], int32_t min_distance, int32_t peak_radius,
                     float threshold_rel, float *flow_out, int64_t channel_stride, int64_t node_begin,
                     void *stream);
+/* m3d_patch_pack + forward transform + m3d_patch_cross_spectrum + inverse transform + m3d_xcorr_peaks in one call for
+ * patches whose transform box is 24 x 64 x 64 (m3d_patch_xcorr_fused_supported): the transforms run in LDS / registers
+ * instead of through rocFFT (same arithmetic up to the rounding of the transforms; replaces the same reference call,
+ * sofima.flow_field.JAXMaskedXCorrWithStatsCalculator.flow_field, utils/sofima_registration.py:670-688).
+ * `work`: m3d_patch_xcorr_fused_workspace_bytes(patch, count) bytes of device memory. */
+int m3d_patch_xcorr_fused_supported(const int32_t patch_zyx[3], const int32_t fft_zyx[3]);
+size_t m3d_patch_xcorr_fused_workspace_bytes(const int32_t patch_zyx[3], int32_t count);
+int m3d_patch_xcorr_fused(const float *pre, const float *post, const int32_t shape_zyx[3],
+                          const int32_t patch_zyx[3], const int32_t step_zyx[3], const int32_t grid_zyx[3],
+                          int64_t node_begin, int32_t count, int32_t min_distance, int32_t peak_radius,
+                          float threshold_rel, void *work, size_t work_bytes, float *flow_out,
+                          int64_t channel_stride, void *stream);
 /* _refine_flow_vectors_subpixel, sofima_registration.py:243-417: for n (node zyx, vector xyz)
  * pairs pick the offset triple (from n_offsets <= 5 host values per axis) minimising the mean
  * squared difference of the normalised post patch and the order-1 sampled pre patch. */

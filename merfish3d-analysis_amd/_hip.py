@@ -161,6 +161,13 @@ _SIGNATURES = {
         c_int,
         [c_void_p, c_int32, _I3, _I3, c_int32, c_int32, c_float, c_void_p, c_int64, c_int64, c_void_p],
     ),
+    "m3d_patch_xcorr_fused_supported": (c_int, [_I3, _I3]),
+    "m3d_patch_xcorr_fused_workspace_bytes": (c_size_t, [_I3, c_int32]),
+    "m3d_patch_xcorr_fused": (
+        c_int,
+        [c_void_p, c_void_p, _I3, _I3, _I3, _I3, c_int64, c_int32, c_int32, c_int32, c_float, c_void_p, c_size_t,
+         c_void_p, c_int64, c_void_p],
+    ),
     "m3d_subpixel_refine": (
         c_int,
         [c_void_p, c_void_p, _I3, _I3, _I3, c_void_p, c_void_p, c_int32, POINTER(c_float), c_int32, c_float,

@@ -22,10 +22,12 @@
 // Flow grids are tiny next to the images (11 x 127 x 127 nodes for a 64 x 2048 x 2048 tile);
 // the cost is the 2 x 177k batched 20 x 64 x 64 transforms, which stream through HBM.
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
 #include "m3d_common.h"
+#include "m3d_fft.h"
 #include "m3d_sample.h"
 
 using namespace m3d;
@@ -108,17 +110,20 @@ __global__ void k_cross_spectrum(float2 *__restrict__ buf, int count, I3 F, floa
 struct PeakGeom {
     I3 F, patch, L;  // FFT box, patch, lag-volume extents 2p-1
 };
-__device__ __forceinline__ float lag_value(const float2 *__restrict__ xc, const PeakGeom &g, int iz, int iy,
-                                           int ix)
+__device__ __forceinline__ float real_of(float2 v) { return v.x; }
+__device__ __forceinline__ float real_of(float v) { return v; }
+template <typename T>
+__device__ __forceinline__ float lag_value(const T *__restrict__ xc, const PeakGeom &g, int iz, int iy, int ix)
 {
     int dz = iz - (g.patch.z - 1), dy = iy - (g.patch.y - 1), dx = ix - (g.patch.x - 1);
     dz = dz < 0 ? dz + g.F.z : dz;
     dy = dy < 0 ? dy + g.F.y : dy;
     dx = dx < 0 ? dx + g.F.x : dx;
-    return xc[((int64_t)dz * g.F.y + dy) * g.F.x + dx].x;
+    return real_of(xc[((int64_t)dz * g.F.y + dy) * g.F.x + dx]);
 }
 
-__global__ void k_xcorr_peaks(const float2 *__restrict__ buf, PeakGeom g, int min_distance, int radius,
+template <typename T>  // float2: the inverse transform's complex output (real part used); float: the real volume
+__global__ void k_xcorr_peaks(const T *__restrict__ buf, PeakGeom g, int min_distance, int radius,
                               float threshold_rel, float *__restrict__ out, int64_t channel_stride,
                               int64_t node_begin)
 {
@@ -126,7 +131,7 @@ __global__ void k_xcorr_peaks(const float2 *__restrict__ buf, PeakGeom g, int mi
     __shared__ int smi[4];
     __shared__ float s_max, s_min;
     __shared__ int s_arg;
-    const float2 *xc = buf + (int64_t)blockIdx.x * g.F.z * g.F.y * g.F.x;
+    const T *xc = buf + (int64_t)blockIdx.x * g.F.z * g.F.y * g.F.x;
     const int nL = g.L.z * g.L.y * g.L.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
@@ -214,6 +219,181 @@ __global__ void k_xcorr_peaks(const float2 *__restrict__ buf, PeakGeom g, int mi
         out[3 * channel_stride + n] = sharp;
         out[4 * channel_stride + n] = ratio;
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fused patch cross-correlation for the common box 24 x 64 x 64 (patch <= 12 x 32 x 32): the rocFFT route above moves a
+// node's 786-KB box through HBM about 25 times (two batched 3-D transforms of five kernels each, pack, cross spectrum,
+// peaks).  Here the transforms run in LDS / registers and a node's data crosses memory four times, in pieces small
+// enough to stay in the infinity cache between kernels:
+//   k_xc_means      patch means (double sums, as k_patch_pack)
+//   k_xc_xy_forward one workgroup per (node, patch plane): gather + mean-subtract + pack pre + i post, 64 x 64 2-D FFT
+//                   in LDS (rows of the zero half skipped), plane -> G[node][pz][ky][kx]
+//   k_xc_z_cross    one workgroup per (node, pair of rows ky, -ky): 24-point FFT along z in registers (planes >= pz are
+//                   zero), Hermitian split + PRE conj(POST) / N against the partner column through LDS, inverse
+//                   24-point FFT -> G2[node][Fz][ky][kx]
+//   k_xc_xy_inverse one workgroup per (node, plane): inverse 2-D FFT in LDS, real part -> X[node][Fz][y][x] float
+//   k_xcorr_peaks<float> on X.
+// Same arithmetic as the rocFFT route up to the rounding of the transforms.
+// ---------------------------------------------------------------------------------------------
+__device__ __constant__ float kCos64[64] = {1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 6.123234e-17f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f, -1.8369702e-16f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f};
+__device__ __constant__ float kSin64[64] = {0.0f, 0.0980171403f, 0.195090322f, 0.290284677f, 0.382683432f, 0.471396737f, 0.555570233f, 0.634393284f, 0.707106781f, 0.773010453f, 0.831469612f, 0.881921264f, 0.923879533f, 0.956940336f, 0.98078528f, 0.995184727f, 1.0f, 0.995184727f, 0.98078528f, 0.956940336f, 0.923879533f, 0.881921264f, 0.831469612f, 0.773010453f, 0.707106781f, 0.634393284f, 0.555570233f, 0.471396737f, 0.382683432f, 0.290284677f, 0.195090322f, 0.0980171403f, 1.2246468e-16f, -0.0980171403f, -0.195090322f, -0.290284677f, -0.382683432f, -0.471396737f, -0.555570233f, -0.634393284f, -0.707106781f, -0.773010453f, -0.831469612f, -0.881921264f, -0.923879533f, -0.956940336f, -0.98078528f, -0.995184727f, -1.0f, -0.995184727f, -0.98078528f, -0.956940336f, -0.923879533f, -0.881921264f, -0.831469612f, -0.773010453f, -0.707106781f, -0.634393284f, -0.555570233f, -0.471396737f, -0.382683432f, -0.290284677f, -0.195090322f, -0.0980171403f};
+constexpr int kXcF = 64, kXcFz = 24, kXcLS = 65;  // lateral box, axial box, LDS row stride (float2)
+
+// x[3a + b] (a < 8, b < 3) -> X[c + 8d] (c < 8, d < 3)
+template <bool INV>
+__device__ __forceinline__ void dft24(float2 *v)
+{
+    const float cs[15][2] = {{1.0f, 0.0f}, {0.965925826f, 0.258819045f}, {0.866025404f, 0.5f}, {0.707106781f, 0.707106781f}, {0.5f, 0.866025404f}, {0.258819045f, 0.965925826f}, {6.123234e-17f, 1.0f}, {-0.258819045f, 0.965925826f}, {-0.5f, 0.866025404f}, {-0.707106781f, 0.707106781f}, {-0.866025404f, 0.5f}, {-0.965925826f, 0.258819045f}, {-1.0f, 1.2246468e-16f}, {-0.965925826f, -0.258819045f}, {-0.866025404f, -0.5f}};
+    float2 u[3][8];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) u[b][a] = v[3 * a + b];
+        dft8<INV>(u[b]);
+    }
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+        u[1][c] = ctw<INV>(u[1][c], cs[c][0], cs[c][1]);
+        u[2][c] = ctw<INV>(u[2][c], cs[2 * c][0], cs[2 * c][1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float2 a0 = u[0][c], a1 = u[1][c], a2 = u[2][c];
+        dft3<INV>(a0, a1, a2);
+        v[c] = a0;
+        v[c + 8] = a1;
+        v[c + 16] = a2;
+    }
+}
+
+// 64-point FFT of up to 64 lines held in LDS, four threads per line (line = tid % 64, l = tid / 64: l is uniform over a
+// wave): element n of a line at base[n * es].  n = l + 4 m, k = k1 + 16 k2:
+//   X[k1 + 16 k2] = sum_l W64^(l k1) W4^(l k2) sum_m x[l + 4 m] W16^(m k1).
+// Natural order in, natural order out, three barriers (all threads of the block must call; `active` masks the work).
+template <bool INV>
+__device__ __forceinline__ void fft64_lines(float2 *base, int es, int l, bool active)
+{
+    float2 v[16];
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = base[(l + 4 * m) * es];
+        dft16<INV>(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const int j = l * k1;  // < 64, uniform over the wave
+            base[(l + 4 * k1) * es] = k1 == 0 ? v[0] : ctw<INV>(v[k1], kCos64[j], kSin64[j]);
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k1 = 4 * q + l;
+#pragma unroll
+            for (int ll = 0; ll < 4; ++ll) v[4 * q + ll] = base[(ll + 4 * k1) * es];
+            dft4<INV>(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);  // X[k1 + 16 k2] at v[4 q + k2]
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) base[(4 * q + l + 16 * k2) * es] = v[4 * q + k2];
+    }
+    __syncthreads();
+}
+
+__global__ void k_xc_means(const float *__restrict__ pre, const float *__restrict__ post, I3 shape, I3 patch, I3 step,
+                           I3 grid, int64_t node_begin, float2 *__restrict__ means)
+{
+    __shared__ double sm[4];
+    const int64_t node = node_begin + blockIdx.x;
+    const int gx = (int)(node % grid.x), gy = (int)((node / grid.x) % grid.y), gz = (int)(node / ((int64_t)grid.x * grid.y));
+    const int z0 = gz * step.z, y0 = gy * step.y, x0 = gx * step.x;
+    const int pv = patch.z * patch.y * patch.x;
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < pv; i += blockDim.x) {
+        const int ux = i % patch.x, uy = (i / patch.x) % patch.y, uz = i / (patch.x * patch.y);
+        const int64_t src = ((int64_t)(z0 + uz) * shape.y + (y0 + uy)) * shape.x + (x0 + ux);
+        sa += (double)pre[src];
+        sb += (double)post[src];
+    }
+    const double ta = block_sum(sa, sm);
+    const double tb = block_sum(sb, sm);
+    if (threadIdx.x == 0) means[blockIdx.x] = make_float2((float)(ta / (double)pv), (float)(tb / (double)pv));
+}
+
+__global__ __launch_bounds__(256) void k_xc_xy_forward(const float *__restrict__ pre, const float *__restrict__ post,
+                                                       I3 shape, I3 patch, I3 step, I3 grid, int64_t node_begin,
+                                                       const float2 *__restrict__ means, float2 *__restrict__ G)
+{
+    __shared__ float2 pl[kXcF * kXcLS];
+    const int tid = threadIdx.x, line = tid & 63, l = tid >> 6;
+    const int nb = blockIdx.x / patch.z, uz = blockIdx.x % patch.z;
+    const int64_t node = node_begin + nb;
+    const int gx = (int)(node % grid.x), gy = (int)((node / grid.x) % grid.y), gz = (int)(node / ((int64_t)grid.x * grid.y));
+    const int z0 = gz * step.z + uz, y0 = gy * step.y, x0 = gx * step.x;
+    const float2 mean = means[nb];
+    for (int i = tid; i < kXcF * kXcF; i += 256) {
+        const int x = i & 63, y = i >> 6;
+        float2 v = make_float2(0.f, 0.f);
+        if (x < patch.x && y < patch.y) {
+            const int64_t src = ((int64_t)z0 * shape.y + (y0 + y)) * shape.x + (x0 + x);
+            v = make_float2(pre[src] - mean.x, post[src] - mean.y);
+        }
+        pl[y * kXcLS + x] = v;
+    }
+    __syncthreads();
+    fft64_lines<false>(pl + line * kXcLS, 1, l, line < patch.y);  // rows: the zero rows transform to zero
+    fft64_lines<false>(pl + line, kXcLS, l, true);                // columns
+    float2 *dst = G + (int64_t)blockIdx.x * (kXcF * kXcF);
+    for (int i = tid; i < kXcF * kXcF; i += 256) dst[i] = pl[(i >> 6) * kXcLS + (i & 63)];
+}
+
+// Z = FFT(a + i b), a and b real:  A(k) = (Z(k) + conj Z(-k)) / 2,  B(k) = (Z(k) - conj Z(-k)) / 2i,  C = A conj(B) / N
+__global__ __launch_bounds__(128) void k_xc_z_cross(const float2 *__restrict__ G, float2 *__restrict__ G2, int pz,
+                                                    float inv_n)
+{
+    __shared__ float2 ex[kXcFz * 128];
+    const int tid = threadIdx.x, kx = tid & 63, rho = tid >> 6;
+    const int nb = blockIdx.x >> 5, r = blockIdx.x & 31;
+    const int ky = r == 0 ? (rho ? 32 : 0) : (rho ? 64 - r : r);
+    const float2 *src = G + ((int64_t)nb * pz * kXcF + ky) * kXcF + kx;
+    float2 v[kXcFz];
+#pragma unroll
+    for (int z = 0; z < kXcFz; ++z) v[z] = z < pz ? src[(int64_t)z * (kXcF * kXcF)] : make_float2(0.f, 0.f);
+    dft24<false>(v);
+#pragma unroll
+    for (int kz = 0; kz < kXcFz; ++kz) ex[kz * 128 + tid] = v[kz];
+    __syncthreads();
+    const int prho = r == 0 ? rho : 1 - rho, pkx = (64 - kx) & 63;
+#pragma unroll
+    for (int kz = 0; kz < kXcFz; ++kz) {
+        const float2 zk = v[kz], zm = ex[((kXcFz - kz) % kXcFz) * 128 + prho * 64 + pkx];
+        const float ar = 0.5f * (zk.x + zm.x), ai = 0.5f * (zk.y - zm.y);
+        const float br = 0.5f * (zk.y + zm.y), bi = -0.5f * (zk.x - zm.x);
+        v[kz] = make_float2((ar * br + ai * bi) * inv_n, (ai * br - ar * bi) * inv_n);
+    }
+    dft24<true>(v);
+    float2 *dst = G2 + ((int64_t)nb * kXcFz * kXcF + ky) * kXcF + kx;
+#pragma unroll
+    for (int z = 0; z < kXcFz; ++z) dst[(int64_t)z * (kXcF * kXcF)] = v[z];
+}
+
+__global__ __launch_bounds__(256) void k_xc_xy_inverse(const float2 *__restrict__ G2, float *__restrict__ X)
+{
+    __shared__ float2 pl[kXcF * kXcLS];
+    const int tid = threadIdx.x, line = tid & 63, l = tid >> 6;
+    const float2 *src = G2 + (int64_t)blockIdx.x * (kXcF * kXcF);
+    for (int i = tid; i < kXcF * kXcF; i += 256) pl[(i >> 6) * kXcLS + (i & 63)] = src[i];
+    __syncthreads();
+    fft64_lines<true>(pl + line, kXcLS, l, true);
+    fft64_lines<true>(pl + line * kXcLS, 1, l, true);
+    float *dst = X + (int64_t)blockIdx.x * (kXcF * kXcF);
+    for (int i = tid; i < kXcF * kXcF; i += 256) dst[i] = pl[(i >> 6) * kXcLS + (i & 63)].x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -363,6 +543,7 @@ struct MeshGeom {
 __constant__ int c_links[9][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0},
                                   {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}};  // xyz
 
+constexpr int kMeshSlots = 64;  // records (4 doubles each) the per-step sums are spread over
 // mode 0: a = F(x) only (initialisation); mode 1: a_new = F(x), v += dt/2 (a + a_new), sums
 __global__ void k_mesh_force(const float *__restrict__ x, const float *__restrict__ prev,
                              float *__restrict__ a, float *__restrict__ v, MeshGeom g, float cap,
@@ -435,9 +616,11 @@ __global__ void k_mesh_force(const float *__restrict__ x, const float *__restric
         const double t1 = block_sum(svv, sm);
         const double t2 = block_sum(saa, sm);
         if (threadIdx.x == 0) {
-            atomicAdd(&sums[0], t0);
-            atomicAdd(&sums[1], t1);
-            atomicAdd(&sums[2], t2);
+            // one of kMeshSlots records: 693 workgroups adding to ONE address serialise (26 of this kernel's 35 us)
+            double *slot = sums + 4 * (blockIdx.x % kMeshSlots);
+            atomicAdd(&slot[0], t0);
+            atomicAdd(&slot[1], t1);
+            atomicAdd(&slot[2], t2);
         }
     }
 }
@@ -458,9 +641,14 @@ __global__ void k_mesh_fire(const float *__restrict__ x_cur, float *__restrict__
     float mix = 0.f;
     bool zero_v = false;
     if (mode == 1) {
-        const double power = sums[0];
-        const float v_norm = (float)sqrt(sums[1]);
-        const float a_norm = (float)sqrt(sums[2] + 1e-6);
+        double power = 0.0, svv = 0.0, saa = 0.0;
+        for (int k = 0; k < kMeshSlots; ++k) {
+            power += sums[4 * k];
+            svv += sums[4 * k + 1];
+            saa += sums[4 * k + 2];
+        }
+        const float v_norm = (float)sqrt(svv);
+        const float a_norm = (float)sqrt(saa + 1e-6);
         mix = v_norm / a_norm;
         const float alpha = s.alpha;  // mixing uses the pre-update alpha
         s.n_pos = power >= 0.0 ? s.n_pos + 1 : 0;
@@ -505,11 +693,9 @@ __global__ void k_mesh_fire(const float *__restrict__ x_cur, float *__restrict__
              i += (int64_t)gridDim.x * blockDim.x)
             x_next[i] = x_cur[i] + dt * v[i] + hdt2 * a[i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *st_out = s;
-        sums_next[0] = 0.0;
-        sums_next[1] = 0.0;
-        sums_next[2] = 0.0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *st_out = s;
+        for (int k = threadIdx.x; k < 4 * kMeshSlots; k += blockDim.x) sums_next[k] = 0.0;
     }
 }
 
@@ -629,9 +815,76 @@ int m3d_xcorr_peaks(const void *buf_c64, int32_t count, const int32_t fft_zyx[3]
     M3D_REQUIRE(g.F.z >= g.L.z && g.F.y >= g.L.y && g.F.x >= g.L.x, "FFT box smaller than the lag volume");
     M3D_REQUIRE((int64_t)g.L.z * g.L.y * g.L.x < (int64_t)1 << 31, "lag volume too large");
     if (count == 0) return M3D_OK;
-    hipLaunchKernelGGL(k_xcorr_peaks, dim3(count), dim3(kBlock), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_xcorr_peaks<float2>, dim3(count), dim3(kBlock), 0, (hipStream_t)stream,
                        (const float2 *)buf_c64, g, min_distance, peak_radius, threshold_rel, flow_out,
                        channel_stride, node_begin);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+size_t m3d_patch_xcorr_fused_workspace_bytes(const int32_t patch_zyx[3], int32_t count)
+{
+    if (!i3_positive(patch_zyx) || count <= 0) return 0;
+    const size_t plane = (size_t)kXcF * kXcF;
+    const size_t a = std::max((size_t)patch_zyx[0] * plane * sizeof(float2), (size_t)kXcFz * plane * sizeof(float));
+    return (size_t)count * (a + (size_t)kXcFz * plane * sizeof(float2) + sizeof(float2)) + 512;
+}
+
+int m3d_patch_xcorr_fused_supported(const int32_t patch_zyx[3], const int32_t fft_zyx[3])
+{
+    return i3_positive(patch_zyx) && i3_positive(fft_zyx) && fft_zyx[0] == kXcFz && fft_zyx[1] == kXcF &&
+           fft_zyx[2] == kXcF && 2 * patch_zyx[0] - 1 <= kXcFz && 2 * patch_zyx[1] - 1 <= kXcF &&
+           2 * patch_zyx[2] - 1 <= kXcF;
+}
+
+int m3d_patch_xcorr_fused(const float *pre, const float *post, const int32_t shape_zyx[3], const int32_t patch_zyx[3],
+                          const int32_t step_zyx[3], const int32_t grid_zyx[3], int64_t node_begin, int32_t count,
+                          int32_t min_distance, int32_t peak_radius, float threshold_rel, void *work, size_t work_bytes,
+                          float *flow_out, int64_t channel_stride, void *stream)
+{
+    M3D_REQUIRE(pre && post && work && flow_out, "null pointer");
+    M3D_REQUIRE(i3_positive(shape_zyx) && i3_positive(patch_zyx) && i3_positive(step_zyx) && i3_positive(grid_zyx),
+                "bad extents");
+    const int32_t fft[3] = {kXcFz, kXcF, kXcF};
+    if (!m3d_patch_xcorr_fused_supported(patch_zyx, fft)) {
+        set_err("m3d_patch_xcorr_fused", "patch does not fit the 24 x 64 x 64 box");
+        return M3D_ERR_UNSUPPORTED;
+    }
+    M3D_REQUIRE(min_distance >= 0 && peak_radius >= 0, "peak windows must be non-negative");
+    M3D_REQUIRE(node_begin >= 0 && count >= 0 && node_begin + count <= channel_stride, "output range");
+    const int64_t nodes = (int64_t)grid_zyx[0] * grid_zyx[1] * grid_zyx[2];
+    M3D_REQUIRE(node_begin + count <= nodes, "node range outside the grid");
+    for (int a = 0; a < 3; ++a)
+        M3D_REQUIRE((int64_t)(grid_zyx[a] - 1) * step_zyx[a] + patch_zyx[a] <= shape_zyx[a], "grid leaves the volume");
+    if (work_bytes < m3d_patch_xcorr_fused_workspace_bytes(patch_zyx, count)) {
+        set_err("workspace", "smaller than m3d_patch_xcorr_fused_workspace_bytes");
+        return M3D_ERR_WORKSPACE;
+    }
+    if (count == 0) return M3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const I3 shape = to_i3(shape_zyx), patch = to_i3(patch_zyx), step = to_i3(step_zyx), grid = to_i3(grid_zyx);
+    const size_t plane = (size_t)kXcF * kXcF;
+    const size_t a_bytes = std::max((size_t)patch.z * plane * sizeof(float2), (size_t)kXcFz * plane * sizeof(float));
+    char *w = (char *)work;
+    float2 *means = (float2 *)w;
+    w += (((size_t)count * sizeof(float2) + 255) / 256) * 256;
+    float2 *G = (float2 *)w;   // [count][pz][64][64] c64, later X [count][24][64][64] f32
+    float *X = (float *)w;
+    w += (size_t)count * a_bytes;
+    float2 *G2 = (float2 *)w;  // [count][24][64][64] c64
+    hipLaunchKernelGGL(k_xc_means, dim3(count), dim3(kBlock), 0, st, pre, post, shape, patch, step, grid, node_begin,
+                       means);
+    hipLaunchKernelGGL(k_xc_xy_forward, dim3(count * patch.z), dim3(256), 0, st, pre, post, shape, patch, step, grid,
+                       node_begin, means, G);
+    hipLaunchKernelGGL(k_xc_z_cross, dim3(count * 32), dim3(128), 0, st, G, G2, patch.z,
+                       1.0f / (float)(kXcFz * kXcF * kXcF));
+    hipLaunchKernelGGL(k_xc_xy_inverse, dim3(count * kXcFz), dim3(256), 0, st, G2, X);
+    PeakGeom g;
+    g.F = I3{kXcFz, kXcF, kXcF};
+    g.patch = patch;
+    g.L = I3{2 * patch.z - 1, 2 * patch.y - 1, 2 * patch.x - 1};
+    hipLaunchKernelGGL(k_xcorr_peaks<float>, dim3(count), dim3(kBlock), 0, st, (const float *)X, g, min_distance,
+                       peak_radius, threshold_rel, flow_out, channel_stride, node_begin);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -857,11 +1110,12 @@ int m3d_subpixel_refine(const float *pre, const float *post, const int32_t shape
     return M3D_OK;
 }
 
+constexpr size_t kMeshScalarBytes = 256 + 2 * 32 * kMeshSlots;  // states, energy / maxima, two sets of sum records
 size_t m3d_mesh_relax_workspace_bytes(const int32_t grid_zyx[3])
 {
     if (!i3_positive(grid_zyx)) return 0;
     const size_t n3 = (size_t)3 * grid_zyx[0] * grid_zyx[1] * grid_zyx[2];
-    return 3 * n3 * sizeof(float) + 256;  // x ping-pong partner, v, a + scalars
+    return 3 * n3 * sizeof(float) + kMeshScalarBytes;  // x ping-pong partner, v, a + scalars
 }
 
 int m3d_mesh_relax(float *x_xyz, const float *prev_xyz, const int32_t grid_zyx[3],
@@ -878,10 +1132,10 @@ int m3d_mesh_relax(float *x_xyz, const float *prev_xyz, const int32_t grid_zyx[3
     }
     hipStream_t st = (hipStream_t)stream;
     const int64_t N = (int64_t)grid_zyx[0] * grid_zyx[1] * grid_zyx[2], N3 = 3 * N;
-    char *scal = (char *)work;  // 256 B of scalars first: the doubles stay 8-byte aligned
-    float *xb = (float *)(scal + 256), *v = xb + N3, *a = v + N3;
+    char *scal = (char *)work;  // scalars first: the doubles stay 8-byte aligned
+    float *xb = (float *)(scal + kMeshScalarBytes), *v = xb + N3, *a = v + N3;
     FireState *state[2] = {(FireState *)scal, (FireState *)(scal + 16)};
-    double *sums[2] = {(double *)(scal + 32), (double *)(scal + 64)};
+    double *sums[2] = {(double *)(scal + 256), (double *)(scal + 256 + 32 * kMeshSlots)};
     double *ekin = (double *)(scal + 96);
     unsigned int *vmax_bits = (unsigned int *)(scal + 104);
     unsigned int *amax_bits = (unsigned int *)(scal + 108);
@@ -910,7 +1164,7 @@ int m3d_mesh_relax(float *x_xyz, const float *prev_xyz, const int32_t grid_zyx[3
     g.k = p->k;
 
     M3D_HIP_CHECK(hipMemsetAsync(v, 0, (size_t)N3 * sizeof(float), st));
-    M3D_HIP_CHECK(hipMemsetAsync(scal, 0, 256, st));
+    M3D_HIP_CHECK(hipMemsetAsync(scal, 0, kMeshScalarBytes, st));
     FireState init = {p->dt, 0.1f, 0, 0};
     M3D_HIP_CHECK(hipMemcpyAsync(state[0], &init, sizeof(init), hipMemcpyHostToDevice, st));
     M3D_HIP_CHECK(hipStreamSynchronize(st));  // `init` is a stack variable

@@ -555,6 +555,36 @@ def xcorr_peaks(buf: torch.Tensor, count: int, fft_zyx, patch_zyx, min_distance:
     return flow_out
 
 
+def patch_xcorr_fused_supported(patch_zyx, fft_zyx) -> bool:
+    """True when the fused cross-correlation kernels cover this patch / transform box (24 x 64 x 64)."""
+    return bool(_hip.lib().m3d_patch_xcorr_fused_supported(_i3(patch_zyx), _i3(fft_zyx)))
+
+
+def patch_xcorr_fused_workspace(patch_zyx, count: int, device) -> torch.Tensor:
+    nbytes = int(_hip.lib().m3d_patch_xcorr_fused_workspace_bytes(_i3(patch_zyx), int(count)))
+    return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+
+
+def patch_xcorr_fused(pre: torch.Tensor, post: torch.Tensor, patch_zyx, step_zyx, grid_zyx, node_begin: int,
+                      node_count: int, min_distance: int, peak_radius: int, threshold_rel: float,
+                      work: torch.Tensor, flow_out: torch.Tensor) -> torch.Tensor:
+    """patch_pack + forward transform + patch_cross_spectrum + inverse transform + xcorr_peaks for ``node_count``
+    nodes in one call, transforms in LDS (``flow_out`` float32 [5, nodes] as for :func:`xcorr_peaks`)."""
+    if pre.dtype != torch.float32 or post.dtype != torch.float32 or pre.shape != post.shape or pre.ndim != 3:
+        raise ValueError("patch_xcorr_fused expects two float32 volumes of the same 3-D shape")
+    if flow_out.dtype != torch.float32 or flow_out.ndim != 2 or flow_out.shape[0] != 5 or \
+            not flow_out.is_contiguous():
+        raise ValueError("flow_out must be contiguous float32 [5, nodes]")
+    pre, post = pre.contiguous(), post.contiguous()
+    with torch.cuda.device(pre.device):
+        _hip.check(_hip.lib().m3d_patch_xcorr_fused(
+            pre.data_ptr(), post.data_ptr(), _i3(pre.shape), _i3(patch_zyx), _i3(step_zyx), _i3(grid_zyx),
+            int(node_begin), int(node_count), int(min_distance), int(peak_radius), float(threshold_rel),
+            work.data_ptr(), int(work.numel()), flow_out.data_ptr(), int(flow_out.shape[1]), _stream(pre)),
+            "m3d_patch_xcorr_fused")
+    return flow_out
+
+
 def subpixel_refine(pre: torch.Tensor, post: torch.Tensor, patch_zyx, step_zyx, nodes_zyx: torch.Tensor,
                     vectors_xyz: torch.Tensor, offsets, epsilon: float) -> torch.Tensor:
     import ctypes

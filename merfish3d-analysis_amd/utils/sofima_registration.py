@@ -19,6 +19,7 @@ NumPy volumes in -> NumPy field out; torch tensors already in HBM are used in pl
 
 from __future__ import annotations
 
+import os
 from dataclasses import asdict, dataclass
 from typing import Any
 
@@ -29,6 +30,8 @@ _CAP_UPSCALE = 10.0
 _PEAK_THRESHOLD_REL = 0.5
 # nodes per rocFFT batch: 1024 x (20 x 64 x 64) complex64 = 640 MiB of HBM
 _XCORR_NODES_PER_BATCH = 1024
+_XCORR_FUSED = os.environ.get("M3D_SOFIMA_FUSED_XCORR", "1") != "0"
+_XCORR_FUSED_NODES_PER_BATCH = int(os.environ.get("M3D_SOFIMA_FUSED_BATCH", "2048"))  # 2.4 GiB of scratch; flat from 1024 up
 
 
 @dataclass(frozen=True)
@@ -237,6 +240,16 @@ def patch_flow_field(pre_image, post_image, *, patch_size, step, peak_min_distan
         raise ValueError(f"patch {patch} larger than the volume {tuple(pre.shape)}")
     nodes = int(np.prod(grid))
     fft = tuple(int(next_gpu_fft_size(2 * p - 1)) for p in patch)
+    if _XCORR_FUSED and kernels.patch_xcorr_fused_supported(patch, fft):
+        # transform box 24 x 64 x 64 (the configured 10 x 32 x 32 patches): transforms in LDS / registers
+        batch = int(min(nodes, batch_nodes or _XCORR_FUSED_NODES_PER_BATCH))
+        work = kernels.patch_xcorr_fused_workspace(patch, batch, pre.device)
+        flow = torch.full((5, nodes), float("nan"), dtype=torch.float32, device=pre.device)
+        for begin in range(0, nodes, batch):
+            kernels.patch_xcorr_fused(pre, post, patch, step, grid, begin, min(batch, nodes - begin),
+                                      peak_min_distance, peak_radius, _PEAK_THRESHOLD_REL, work, flow)
+        del work
+        return flow.cpu().numpy().reshape((5,) + grid)
     batch = int(min(nodes, batch_nodes or _XCORR_NODES_PER_BATCH))
     plan = kernels.FFTPlan(fft, pre.device, batch=batch)
     try:

@@ -44,6 +44,31 @@ def test_patch_flow_field_matches_oracle(shape, patch, step, batch):
     assert np.array_equal(got[4] == 0, ref[4] == 0)
 
 
+def test_fused_cross_correlation_equals_the_rocfft_route():
+    """Transform box 24 x 64 x 64 (the configured 10 x 32 x 32 patches): the LDS / register transforms of
+    m3d_patch_xcorr_fused against pack -> rocFFT -> cross spectrum -> rocFFT -> peaks on the same volumes."""
+    sf = pkg("utils.sofima_registration")
+    kernels = pkg("kernels")
+    patch, step = (10, 32, 32), (5, 16, 16)
+    assert kernels.patch_xcorr_fused_supported(patch, (24, 64, 64))
+    assert not kernels.patch_xcorr_fused_supported((6, 12, 12), (12, 24, 24))
+    fixed, moving = _textured_pair((26, 150, 178), seed=11, shift=(0.0, 3.0, -2.0))
+    pre, post = torch.from_numpy(moving).to(DEV), torch.from_numpy(fixed).to(DEV)
+    kw = dict(patch_size=patch, step=step, peak_min_distance=2, peak_radius=8)
+    assert sf._XCORR_FUSED
+    fused = sf.patch_flow_field(pre, post, batch_nodes=37, **kw)       # ragged last batch
+    try:
+        sf._XCORR_FUSED = False
+        plain = sf.patch_flow_field(pre, post, **kw)
+    finally:
+        sf._XCORR_FUSED = True
+    assert fused.shape == plain.shape == (5, 4, 8, 10)
+    np.testing.assert_array_equal(fused[:3], plain[:3])
+    np.testing.assert_allclose(fused[3], plain[3], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(fused[4], plain[4], rtol=1e-3, atol=1e-3)
+    assert np.abs(fused[:3]).max() > 0
+
+
 def test_clean_flow_is_the_oracle_rule():
     sf = pkg("utils.sofima_registration")
     rng = np.random.default_rng(2)
