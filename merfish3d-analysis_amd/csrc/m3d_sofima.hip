@@ -136,14 +136,41 @@ __global__ void k_xcorr_peaks(const T *__restrict__ buf, PeakGeom g, int min_dis
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
     // global maximum, first index on ties (np.argmax)
+    // one wave per lag row (iz, iy): the row's index arithmetic is done once, the lanes run along x; four rows are
+    // requested before the first is compared (one load in flight per lane made this kernel latency bound)
+    const int nrows = g.L.z * g.L.y, nwaves = (int)(blockDim.x >> 6);
+    auto row_of = [&](int r) -> const T * {
+        const int iz = r / g.L.y, iy = r - iz * g.L.y;
+        int dz = iz - (g.patch.z - 1), dy = iy - (g.patch.y - 1);
+        dz = dz < 0 ? dz + g.F.z : dz;
+        dy = dy < 0 ? dy + g.F.y : dy;
+        return xc + ((int64_t)dz * g.F.y + dy) * g.F.x;
+    };
+    constexpr int kRowsInFlight = 4;
     float bv = -INFINITY;
     int bi = nL;
-    for (int i = threadIdx.x; i < nL; i += blockDim.x) {
-        const int ix = i % g.L.x, iy = (i / g.L.x) % g.L.y, iz = i / (g.L.x * g.L.y);
-        const float v = lag_value(xc, g, iz, iy, ix);
-        if (v > bv || (v == bv && i < bi)) {
-            bv = v;
-            bi = i;
+    for (int ixb = 0; ixb < g.L.x; ixb += 64) {
+        const int ix = ixb + lane;
+        int dx = ix - (g.patch.x - 1);
+        dx = dx < 0 ? dx + g.F.x : dx;
+        const bool x_ok = ix < g.L.x;
+        for (int r0 = w; r0 < nrows; r0 += nwaves * kRowsInFlight) {
+            float vv[kRowsInFlight];
+#pragma unroll
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                const int r = min(r0 + u * nwaves, nrows - 1);
+                vv[u] = x_ok ? real_of(row_of(r)[dx]) : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                const int r = r0 + u * nwaves;
+                if (r >= nrows || !x_ok) continue;
+                const int i = r * g.L.x + ix;
+                if (vv[u] > bv || (vv[u] == bv && i < bi)) {
+                    bv = vv[u];
+                    bi = i;
+                }
+            }
         }
     }
 #pragma unroll
@@ -190,23 +217,40 @@ __global__ void k_xcorr_peaks(const T *__restrict__ buf, PeakGeom g, int min_dis
     // outside the peak window
     const float thr = threshold_rel * vmax;
     float second = -INFINITY;
-    for (int i = threadIdx.x; i < nL; i += blockDim.x) {
-        const int ix = i % g.L.x, iy = (i / g.L.x) % g.L.y, iz = i / (g.L.x * g.L.y);
-        if (iz >= wz0 && iz < wz1 && iy >= wy0 && iy < wy1 && ix >= wx0 && ix < wx1) continue;
-        const float v = lag_value(xc, g, iz, iy, ix);
-        if (!(v > thr) || !(v > second)) continue;
-        bool is_peak = true;
-        const int nz0 = max(0, iz - min_distance), nz1 = min(g.L.z, iz + min_distance + 1);
-        const int ny0 = max(0, iy - min_distance), ny1 = min(g.L.y, iy + min_distance + 1);
-        const int nx0 = max(0, ix - min_distance), nx1 = min(g.L.x, ix + min_distance + 1);
-        for (int a = nz0; a < nz1 && is_peak; ++a)
-            for (int b = ny0; b < ny1 && is_peak; ++b)
-                for (int c = nx0; c < nx1; ++c)
-                    if (lag_value(xc, g, a, b, c) > v) {
-                        is_peak = false;
-                        break;
-                    }
-        if (is_peak) second = v;
+    for (int ixb = 0; ixb < g.L.x; ixb += 64) {
+        const int ix = ixb + lane;
+        int dx = ix - (g.patch.x - 1);
+        dx = dx < 0 ? dx + g.F.x : dx;
+        const bool x_ok = ix < g.L.x;
+        for (int r0 = w; r0 < nrows; r0 += nwaves * kRowsInFlight) {
+            float vv[kRowsInFlight];
+#pragma unroll
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                const int r = min(r0 + u * nwaves, nrows - 1);
+                vv[u] = x_ok ? real_of(row_of(r)[dx]) : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsInFlight; ++u) {
+                const int r = r0 + u * nwaves;
+                if (r >= nrows || !x_ok) continue;
+                const int iz = r / g.L.y, iy = r - iz * g.L.y;
+                if (iz >= wz0 && iz < wz1 && iy >= wy0 && iy < wy1 && ix >= wx0 && ix < wx1) continue;
+                const float v = vv[u];
+                if (!(v > thr) || !(v > second)) continue;
+                bool is_peak = true;
+                const int nz0 = max(0, iz - min_distance), nz1 = min(g.L.z, iz + min_distance + 1);
+                const int ny0 = max(0, iy - min_distance), ny1 = min(g.L.y, iy + min_distance + 1);
+                const int nx0 = max(0, ix - min_distance), nx1 = min(g.L.x, ix + min_distance + 1);
+                for (int a = nz0; a < nz1 && is_peak; ++a)
+                    for (int b = ny0; b < ny1 && is_peak; ++b)
+                        for (int c = nx0; c < nx1; ++c)
+                            if (lag_value(xc, g, a, b, c) > v) {
+                                is_peak = false;
+                                break;
+                            }
+                if (is_peak) second = v;
+            }
+        }
     }
     second = block_max(second, smv);
     if (threadIdx.x == 0) {
@@ -379,20 +423,25 @@ __global__ __launch_bounds__(128) void k_xc_z_cross(const float2 *__restrict__ G
     }
     dft24<true>(v);
     float2 *dst = G2 + ((int64_t)nb * kXcFz * kXcF + ky) * kXcF + kx;
+    // only the planes that hold lags -(pz - 1) .. pz - 1 are read again
 #pragma unroll
-    for (int z = 0; z < kXcFz; ++z) dst[(int64_t)z * (kXcF * kXcF)] = v[z];
+    for (int z = 0; z < kXcFz; ++z)
+        if (z < pz || z > kXcFz - pz) dst[(int64_t)z * (kXcF * kXcF)] = v[z];
 }
 
-__global__ __launch_bounds__(256) void k_xc_xy_inverse(const float2 *__restrict__ G2, float *__restrict__ X)
+__global__ __launch_bounds__(256) void k_xc_xy_inverse(const float2 *__restrict__ G2, float *__restrict__ X, int pz)
 {
     __shared__ float2 pl[kXcF * kXcLS];
     const int tid = threadIdx.x, line = tid & 63, l = tid >> 6;
-    const float2 *src = G2 + (int64_t)blockIdx.x * (kXcF * kXcF);
+    // the 2 pz - 1 planes of lags -(pz - 1) .. pz - 1: box planes 0 .. pz - 1 and Fz - (pz - 1) .. Fz - 1
+    const int nlag = 2 * pz - 1, nb = blockIdx.x / nlag, q = blockIdx.x % nlag;
+    const int64_t plane = (int64_t)nb * kXcFz + (q < pz ? q : kXcFz - nlag + q);
+    const float2 *src = G2 + plane * (kXcF * kXcF);
     for (int i = tid; i < kXcF * kXcF; i += 256) pl[(i >> 6) * kXcLS + (i & 63)] = src[i];
     __syncthreads();
     fft64_lines<true>(pl + line, kXcLS, l, true);
     fft64_lines<true>(pl + line * kXcLS, 1, l, true);
-    float *dst = X + (int64_t)blockIdx.x * (kXcF * kXcF);
+    float *dst = X + plane * (kXcF * kXcF);
     for (int i = tid; i < kXcF * kXcF; i += 256) dst[i] = pl[(i >> 6) * kXcLS + (i & 63)].x;
 }
 
@@ -543,7 +592,7 @@ struct MeshGeom {
 __constant__ int c_links[9][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, -1, 0},
                                   {1, 0, 1}, {1, 0, -1}, {0, 1, 1}, {0, 1, -1}};  // xyz
 
-constexpr int kMeshSlots = 64;  // records (4 doubles each) the per-step sums are spread over
+constexpr int kMeshSlots = 16;  // records (4 doubles each) the per-step sums are spread over (64: the readers get slower)
 // mode 0: a = F(x) only (initialisation); mode 1: a_new = F(x), v += dt/2 (a + a_new), sums
 __global__ void k_mesh_force(const float *__restrict__ x, const float *__restrict__ prev,
                              float *__restrict__ a, float *__restrict__ v, MeshGeom g, float cap,
@@ -878,7 +927,7 @@ int m3d_patch_xcorr_fused(const float *pre, const float *post, const int32_t sha
                        node_begin, means, G);
     hipLaunchKernelGGL(k_xc_z_cross, dim3(count * 32), dim3(128), 0, st, G, G2, patch.z,
                        1.0f / (float)(kXcFz * kXcF * kXcF));
-    hipLaunchKernelGGL(k_xc_xy_inverse, dim3(count * kXcFz), dim3(256), 0, st, G2, X);
+    hipLaunchKernelGGL(k_xc_xy_inverse, dim3(count * (2 * patch.z - 1)), dim3(256), 0, st, G2, X, patch.z);
     PeakGeom g;
     g.F = I3{kXcFz, kXcF, kXcF};
     g.patch = patch;
