@@ -942,23 +942,54 @@ int m3d_patch_xcorr_fused(const float *pre, const float *post, const int32_t sha
     return M3D_OK;
 }
 
-// Three offsets per axis whose span fits a three-point window (the configured -0.5, 0, 0.5): all 27 candidates in ONE
-// pass over the patch.  Order-1 interpolation is separable and its weights are the same for every voxel of a patch,
-// so a voxel's 27 samples come from its 3 x 3 x 3 window neighbourhood through three small contractions (x, y, z:
-// 81 fused multiply-adds each) instead of 27 x 8 gathers, and the normalised SSD of :373-399 follows from five running
-// sums per candidate,
-//     score = var_s / sd_s^2 + var_p / sd_p^2 - 2 cov / (sd_s sd_p),    sd = max(sqrt(var), eps),
-// (= mean(((S - mean S) / sd_s - (P - mean P) / sd_p)^2) expanded), accumulated on values shifted by the window mean
-// so that the variances are not differences of large numbers.  Per-thread float partials (40 voxels), wave butterfly in
-// float, the four wave partials and the final arithmetic in double.
+// Three offsets per axis whose span fits a three-point window (the configured -0.5, 0, 0.5): all 27 candidates share
+// their gathers.  Order-1 interpolation is separable and its weights are the same for every voxel of a patch, so a
+// voxel's 27 samples come from its 3 x 3 x 3 window neighbourhood through three small contractions (x, y, z: 81 fused
+// multiply-adds each) instead of 27 x 8 gathers.  Two sweeps over the patch: the first collects sum and sum of squares
+// per candidate (mean, deviation), the second the normalised squared difference itself,
+//     score = mean(((S - mean S) / sd_s - (P - mean P) / sd_p)^2),    sd = max(sqrt(var), eps)     (:373-399)
+// in that form - NOT expanded into 2 - 2 corr, which loses the tiny positive scores of almost-identical candidates to
+// rounding and then prefers them to an exactly matching one.  Values are shifted by the window mean first so that
+// the variances are not differences of large numbers.
+__device__ __forceinline__ void sample27(const float *__restrict__ w0, int Ry, int Rx, const float (&wz)[3][3],
+                                         const float (&wy)[3][3], const float (&wx)[3][3], float (&S)[27])
+{
+    float B[3][3][3];  // [window z][candidate y][candidate x]
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float Ar[3][3];  // [window y][candidate x]
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float *r = w0 + (a * Ry + b) * Rx;
+            const float c0 = r[0], c1 = r[1], c2 = r[2];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) Ar[b][kx] = c0 * wx[kx][0] + c1 * wx[kx][1] + c2 * wx[kx][2];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                B[a][ky][kx] = Ar[0][kx] * wy[ky][0] + Ar[1][kx] * wy[ky][1] + Ar[2][kx] * wy[ky][2];
+    }
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                S[(kz * 3 + ky) * 3 + kx] =
+                    B[0][ky][kx] * wz[kz][0] + B[1][ky][kx] * wz[kz][1] + B[2][ky][kx] * wz[kz][2];
+}
+
 __global__ __launch_bounds__(256) void k_subpixel_refine3(const float *__restrict__ pre, const float *__restrict__ post,
                                                           RefineArgs A, const int *__restrict__ nodes,
                                                           const float *__restrict__ vec, float *__restrict__ out)
 {
-    extern __shared__ float win[];  // pre window minus its mean; afterwards the wave partials
+    extern __shared__ float win[];  // pre window minus its mean
     __shared__ double smd[4];
     __shared__ float s_m0;
-    __shared__ double s_sum[83];
+    __shared__ float s_part[4][56];
+    __shared__ float s_mean[28], s_rsd[28];  // per candidate, [27] = the post patch
     const int n = blockIdx.x, tid = threadIdx.x;
     const int pv = A.patch.z * A.patch.y * A.patch.x;
     const int gz = nodes[3 * n + 0], gy = nodes[3 * n + 1], gx = nodes[3 * n + 2];
@@ -1012,92 +1043,109 @@ __global__ __launch_bounds__(256) void k_subpixel_refine3(const float *__restric
             wx[k][j] = j == lx ? 1.f - tx : (j == lx + 1 ? tx : 0.f);
         }
     }
+    const int px = A.patch.x, py = A.patch.y;
+    const int qx = 256 % px, qy = (256 / px) % py, qz = 256 / (px * py);
+    const int ux0 = tid % px, uy0 = (tid / px) % py, uz0 = tid / (px * py);
+    auto advance = [&](int &ux, int &uy, int &uz) {
+        ux += qx;
+        int c = ux >= px ? 1 : 0;
+        ux -= c ? px : 0;
+        uy += qy + c;
+        c = uy >= py ? 1 : 0;
+        uy -= c ? py : 0;
+        uz += qz + c;
+    };
+    auto post_at = [&](int uz, int uy, int ux) -> float {
+        const int z = sz + uz, y = sy + uy, x = sx + ux;
+        float pval = 0.f;
+        if (z < A.shape.z && y < A.shape.y && x < A.shape.x) pval = post[((int64_t)z * A.shape.y + y) * A.shape.x + x];
+        return pval - m0;
+    };
+    const int lane = tid & 63, wv = tid >> 6;
+    const float inv = 1.0f / (float)pv;
 
-    float s1[27], s2[27], sp[27], p1 = 0.f, p2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < 27; ++c) s1[c] = s2[c] = sp[c] = 0.f;
+    // sweep 1: sum and sum of squares of every candidate and of the post patch
     {
-        const int px = A.patch.x, py = A.patch.y;
-        int ux = tid % px, uy = (tid / px) % py, uz = tid / (px * py);
-        const int qx = 256 % px, qy = (256 / px) % py, qz = 256 / (px * py);
+        float s1[28], s2[28];
+#pragma unroll
+        for (int c = 0; c < 28; ++c) s1[c] = s2[c] = 0.f;
+        int ux = ux0, uy = uy0, uz = uz0;
         for (int i = tid; i < pv; i += 256) {
-            const int z = sz + uz, y = sy + uy, x = sx + ux;
-            float pval = 0.f;
-            if (z < A.shape.z && y < A.shape.y && x < A.shape.x) pval = post[((int64_t)z * A.shape.y + y) * A.shape.x + x];
-            const float P = pval - m0;
-            p1 += P;
-            p2 += P * P;
-            const float *w0 = win + (uz * Ry + uy) * Rx + ux;
-            float B[3][3][3];  // [window z][candidate y][candidate x]
+            float S[27];
+            sample27(win + (uz * Ry + uy) * Rx + ux, Ry, Rx, wz, wy, wx, S);
+            const float P = post_at(uz, uy, ux);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float Ar[3][3];  // [window y][candidate x]
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const float *r = w0 + (a * Ry + b) * Rx;
-                    const float c0 = r[0], c1 = r[1], c2 = r[2];
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) Ar[b][kx] = c0 * wx[kx][0] + c1 * wx[kx][1] + c2 * wx[kx][2];
-                }
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        B[a][ky][kx] = Ar[0][kx] * wy[ky][0] + Ar[1][kx] * wy[ky][1] + Ar[2][kx] * wy[ky][2];
+            for (int c = 0; c < 27; ++c) {
+                s1[c] += S[c];
+                s2[c] += S[c] * S[c];
             }
-#pragma unroll
-            for (int kz = 0; kz < 3; ++kz)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float S = B[0][ky][kx] * wz[kz][0] + B[1][ky][kx] * wz[kz][1] + B[2][ky][kx] * wz[kz][2];
-                        const int c = (kz * 3 + ky) * 3 + kx;
-                        s1[c] += S;
-                        s2[c] += S * S;
-                        sp[c] += S * P;
-                    }
-            ux += qx;
-            int c = ux >= px ? 1 : 0;
-            ux -= c ? px : 0;
-            uy += qy + c;
-            c = uy >= py ? 1 : 0;
-            uy -= c ? py : 0;
-            uz += qz + c;
+            s1[27] += P;
+            s2[27] += P * P;
+            advance(ux, uy, uz);
         }
+#pragma unroll
+        for (int c = 0; c < 28; ++c) {
+            s1[c] = wave_sum(s1[c]);
+            s2[c] = wave_sum(s2[c]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 28; ++c) {
+                s_part[wv][c] = s1[c];
+                s_part[wv][28 + c] = s2[c];
+            }
+        }
+        __syncthreads();
+        if (tid < 28) {
+            const double a = (double)s_part[0][tid] + (double)s_part[1][tid] + (double)s_part[2][tid] + (double)s_part[3][tid];
+            const double b = (double)s_part[0][28 + tid] + (double)s_part[1][28 + tid] + (double)s_part[2][28 + tid] +
+                             (double)s_part[3][28 + tid];
+            const double mean = a * (double)inv, var = fmax(b * (double)inv - mean * mean, 0.0);
+            s_mean[tid] = (float)mean;
+            s_rsd[tid] = 1.0f / fmaxf((float)sqrt(var), A.eps);
+        }
+        __syncthreads();
     }
-    __syncthreads();  // every thread is done with the window: it becomes the wave partials [4][83]
+
+    // sweep 2: the normalised squared differences
+    float mean_c[27], rsd_c[27];
 #pragma unroll
     for (int c = 0; c < 27; ++c) {
-        s1[c] = wave_sum(s1[c]);
-        s2[c] = wave_sum(s2[c]);
-        sp[c] = wave_sum(sp[c]);
+        mean_c[c] = s_mean[c];
+        rsd_c[c] = s_rsd[c];
     }
-    p1 = wave_sum(p1);
-    p2 = wave_sum(p2);
-    if ((tid & 63) == 0) {
-        float *dst = win + (tid >> 6) * 83;
+    const float mean_p = s_mean[27], rsd_p = s_rsd[27];
+    float sc[27];
 #pragma unroll
-        for (int c = 0; c < 27; ++c) {
-            dst[c] = s1[c];
-            dst[27 + c] = s2[c];
-            dst[54 + c] = sp[c];
+    for (int c = 0; c < 27; ++c) sc[c] = 0.f;
+    {
+        int ux = ux0, uy = uy0, uz = uz0;
+        for (int i = tid; i < pv; i += 256) {
+            float S[27];
+            sample27(win + (uz * Ry + uy) * Rx + ux, Ry, Rx, wz, wy, wx, S);
+            const float pn = (post_at(uz, uy, ux) - mean_p) * rsd_p;
+#pragma unroll
+            for (int c = 0; c < 27; ++c) {
+                const float q = (S[c] - mean_c[c]) * rsd_c[c] - pn;
+                sc[c] += q * q;
+            }
+            advance(ux, uy, uz);
         }
-        dst[81] = p1;
-        dst[82] = p2;
     }
-    __syncthreads();
-    if (tid < 83) s_sum[tid] = (double)win[tid] + (double)win[83 + tid] + (double)win[166 + tid] + (double)win[249 + tid];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) sc[c] = wave_sum(sc[c]);
+    __syncthreads();  // s_part is reused
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 27; ++c) s_part[wv][c] = sc[c];
+    }
     __syncthreads();
     if (tid == 0) {
-        const double inv = 1.0 / (double)pv, eps = (double)A.eps;
-        const double mp = s_sum[81] * inv, varp = fmax(s_sum[82] * inv - mp * mp, 0.0), sdp = fmax(sqrt(varp), eps);
         int best = 0;
         float best_score = 0.f;
         for (int c = 0; c < 27; ++c) {
-            const double ms = s_sum[c] * inv, vars = fmax(s_sum[27 + c] * inv - ms * ms, 0.0);
-            const double sds = fmax(sqrt(vars), eps), cov = s_sum[54 + c] * inv - ms * mp;
-            const float score = (float)(vars / (sds * sds) + varp / (sdp * sdp) - 2.0 * cov / (sds * sdp));
+            const float score = (float)(((double)s_part[0][c] + (double)s_part[1][c] + (double)s_part[2][c] +
+                                         (double)s_part[3][c]) * (double)inv);
             if (c == 0 || score < best_score) {  // first minimum (argmin)
                 best = c;
                 best_score = score;
@@ -1146,7 +1194,7 @@ int m3d_subpixel_refine(const float *pre, const float *post, const int32_t shape
     // three offsets over a three-point window: the one-pass kernel (window only in LDS: two workgroups per CU)
     static const bool one_pass_ok = !(getenv("M3D_SUBPIXEL_ONE_PASS") && atoi(getenv("M3D_SUBPIXEL_ONE_PASS")) == 0);
     const size_t win_bytes = sizeof(float) * (size_t)A.region.z * A.region.y * A.region.x;
-    if (one_pass_ok && n_offsets == 3 && extra == 3 && win_bytes >= sizeof(float) * 4 * 83 &&
+    if (one_pass_ok && n_offsets == 3 && extra == 3 && 
         offsets_host[0] <= offsets_host[1] && offsets_host[1] <= offsets_host[2]) {
         M3D_HIP_CHECK(hipFuncSetAttribute((const void *)k_subpixel_refine3,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)win_bytes));
