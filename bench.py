@@ -359,6 +359,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config2")
     ap.add_argument("--tiles", type=int, default=8, help="config3: tiles of the volume (fixed as N grows)")
+    ap.add_argument("--sofima", action="store_true",
+                    help="config3: also run the SOFIMA residual-flow estimator per moving round (configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -397,6 +399,7 @@ def main() -> int:
     kernels = importlib.import_module("merfish3d-analysis_amd.kernels")
     rl = importlib.import_module("merfish3d-analysis_amd.utils.rlgc")
     mv = importlib.import_module("merfish3d-analysis_amd.utils.multiview_registration")
+    sofima = importlib.import_module("merfish3d-analysis_amd.utils.sofima_registration")
     PD = importlib.import_module("merfish3d-analysis_amd.PixelDecoder")
     DS = importlib.import_module("merfish3d-analysis_amd.datastore")
     scoring = importlib.import_module("merfish3d-analysis_amd.scoring")
@@ -490,6 +493,17 @@ def main() -> int:
             err = np.abs(T[:3, 3] / np.asarray(spacing) - current["shifts"][r]).max()
             stats["reg_err_px"] = max(stats["reg_err_px"], float(err))
             progress(f"round {r + 1}/{n_rounds}: {info.iterations} RLGC iterations, shift error {err:.3f} px")
+            if args.sofima:
+                # DataRegistration._process_sofima_rounds_on_gpu (:561-693): residual flow after the affine
+                t0 = time.perf_counter()
+                initialized = mv.warp_array_to_reference_gpu(moving, transform_zyx_um=np.asarray(T, dtype=np.float32),
+                                                             spacing_zyx_um=spacing, reference_shape=shape)
+                _flow, md = sofima.estimate_sofima_flow_field_xyz_px(reference, initialized)
+                torch.cuda.synchronize(device)
+                stats["sofima_s"] = stats.get("sofima_s", 0.0) + time.perf_counter() - t0
+                stats["sofima_calls"] = stats.get("sofima_calls", 0) + 1
+                stats["sofima_status"] = md["status"]
+                del initialized, _flow
 
     def deconvolve_bits(profile: bool) -> None:
         for b in range(n_bits):  # DataRegistration._apply_bits_on_gpu: decon -> clip -> uint16
@@ -653,6 +667,12 @@ def main() -> int:
                 "calls_rank0": stats["reg_calls"], "avg_s": round(stats["reg_s"] / stats["reg_calls"], 4),
                 "max_s": round(stats.get("reg_max_s", 0.0), 4),
                 "max_shift_error_px": round(stats["reg_err_px"], 4)}
+        if strong and stats.get("sofima_calls"):
+            out["sofima"] = {
+                "what": "affine warp + estimate_sofima_flow_field_xyz_px per moving round (two residual passes; host "
+                        "wall time; the flow is not applied: the synthetic rounds are pure translations)",
+                "calls_rank0": stats["sofima_calls"], "avg_s": round(stats["sofima_s"] / stats["sofima_calls"], 4),
+                "last_status": stats.get("sofima_status")}
         # sanity of the decoded table against the planted emitters (voxel units, 3-voxel radius, same
         # codeword, one-to-one): the scorer of the simulation pipeline, not a timed quantity
         table = stats.get("table")
