@@ -97,6 +97,11 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
 // scratch spectrum `spec_alt` only the box's own rows are transformed along x (mirrored rows have the
 // same transform) and the Y pass assembles every plane from the core plane it mirrors.
 
+// |OTF|^2 as a float volume (same plane order as the OTF): the consensus convolution (mode 2) then reads half the
+// transfer-function bytes.  Pass it as `otf` with mode 3; needs the register Z pass (fftconv_real_otf_supported).
+bool fftconv_real_otf_supported(const FftConvPlan *p);
+int fftconv_otf_abs2(const FftConvPlan *p, const float2 *otf, float *out, void *stream);
+
 // fftconv_to_rows for two inputs that take the same transfer function (the two HTratio convolutions of an RLGC
 // iteration): the Z pass of both runs as one launch that reads each OTF line from HBM once.
 int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *src2, const float2 *otf, int mode,

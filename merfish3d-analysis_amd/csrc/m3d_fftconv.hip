@@ -1469,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_z_conv(float2 *__restrict__ spec, const
 // by this kernel's own mode -1.
 // ZM: what lies outside the input's planes - 0 zero, 1 symmetric extension (general), 2 symmetric extension with one
 // reflection (pad no deeper than the core).  OUTF: every plane of the output is stored (no per-plane test).
-template <int L, int P, int ZM = 1, bool OUTF = false>
+template <int L, int P, int ZM = 1, bool OUTF = false, bool REALH = false>
 __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__restrict__ spec, const float2 *__restrict__ otf,
                                                        ConvGeo g, const float2 *__restrict__ tw, int mode, float scale,
                                                        float2 *__restrict__ spec_b = nullptr)
@@ -1498,12 +1498,23 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
     (void)N;
 
     float2 h[16];  // transfer function at k = (l + b L) + 16 k2
-    if (M3D_ZREG_OTF_EARLY && mode >= 0) {  // requested before anything else
+    // mode 3: `otf` is a float volume of the same plane order that holds |H|^2 (half the bytes of mode 2)
+    auto load_otf = [&]() {  // REALH: its own instantiation, the other variants keep their code
+        if constexpr (REALH) {
+            const float *of = reinterpret_cast<const float *>(otf);
 #pragma unroll
-        for (int b = 0; b < NBF; ++b)
+            for (int b = 0; b < NBF; ++b)
 #pragma unroll
-            for (int k2 = 0; k2 < L; ++k2) h[b * L + k2] = otf[pc + (int64_t)((l + b * L) + 16 * k2) * g.plane];
-    }
+                for (int k2 = 0; k2 < L; ++k2)
+                    h[b * L + k2] = make_float2(of[pc + (int64_t)((l + b * L) + 16 * k2) * g.plane], 0.0f);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NBF; ++b)
+#pragma unroll
+                for (int k2 = 0; k2 < L; ++k2) h[b * L + k2] = otf[pc + (int64_t)((l + b * L) + 16 * k2) * g.plane];
+        }
+    };
+    if (M3D_ZREG_OTF_EARLY && mode >= 0) load_otf();  // requested before anything else
     float2 v[16];
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -1538,12 +1549,7 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
     ex[l * P + p] = v[0];
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) ex[k1 * KS + l * P + p] = cmul(v[k1], w[k1]);
-    if (!M3D_ZREG_OTF_EARLY && mode >= 0) {  // requested once the 16 samples are out of the registers
-#pragma unroll
-        for (int b = 0; b < NBF; ++b)
-#pragma unroll
-            for (int k2 = 0; k2 < L; ++k2) h[b * L + k2] = otf[pc + (int64_t)((l + b * L) + 16 * k2) * g.plane];
-    }
+    if (!M3D_ZREG_OTF_EARLY && mode >= 0) load_otf();  // requested once the 16 samples are out of the registers
     __syncthreads();
     float2 y[16];
 #pragma unroll
@@ -1564,6 +1570,10 @@ __global__ __launch_bounds__(P * L) M3D_ZREG_ATTR void k_z_conv_reg(float2 *__re
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float2 hh = h[i];
+        if constexpr (REALH) {  // same two roundings as cmul with a zero imaginary part, then the scale
+            y[i] = make_float2(y[i].x * hh.x * scale, y[i].y * hh.x * scale);
+            continue;
+        }
         if (mode == 1) hh.y = -hh.y;
         if (mode == 2) hh = make_float2(hh.x * hh.x + hh.y * hh.y, 0.0f);
         const float2 t = cmul(y[i], hh);
@@ -1860,6 +1870,12 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
                      hipStream_t st, float2 *spec_b = nullptr)
 {
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
+    // a real |OTF|^2 volume (mode 3) exists for the register Z pass with zero-extended input and cropped output (the
+    // consensus convolution); callers check fftconv_real_otf_supported and pass it for that geometry only
+    if (mode == 3 && (!p->zreg || g.zmirror || (g.out.z0 == 0 && g.out.nz == p->Zp))) {
+        set_err("fftconv", "mode 3 outside the geometry it is built for");
+        return;
+    }
     if (!p->zreg && spec_b) {  // the LDS variant has no paired form
         launch_z(p, spec, otf, g, mode, scale, st);
         launch_z(p, spec_b, otf, g, mode, scale, st);
@@ -1881,6 +1897,8 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
             hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 1, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
         else if (outf)                                                                                                \
             hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, true>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b);  \
+        else if (mode == 3)                                                                                           \
+            hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, false, true>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
         else                                                                                                          \
             hipLaunchKernelGGL((k_z_conv_reg<LL, PP, 0, false>), dim3(nb), dim3(PP * LL), 0, st, spec, otf, g, p->az.tw, mode, scale, spec_b); \
     } while (0)
@@ -2017,6 +2035,25 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
     launch_y_pass<true>(p, spec, g, g.out.nz, st);
     if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+bool fftconv_real_otf_supported(const FftConvPlan *p) { return p && p->zreg != 0; }
+
+__global__ void k_otf_abs2(const float2 *__restrict__ otf, float *__restrict__ out, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float2 h = otf[i];
+        out[i] = h.x * h.x + h.y * h.y;  // the arithmetic of mode 2
+    }
+}
+int fftconv_otf_abs2(const FftConvPlan *p, const float2 *otf, float *out, void *stream)
+{
+    if (!p || !otf || !out) return M3D_ERR_INVALID_ARG;
+    const int64_t n = (int64_t)p->Zp * p->plane;
+    hipLaunchKernelGGL(k_otf_abs2, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0,
+                       (hipStream_t)stream, otf, out, n);
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }

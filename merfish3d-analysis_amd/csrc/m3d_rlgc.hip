@@ -550,6 +550,7 @@ struct m3d_rlgc_plan {
     size_t spec_bytes = 0;
     size_t workspace = 0;
     // workspace offsets
+    size_t o_otf2 = 0;  // |OTF|^2 as float (fused engine with the register Z pass), 0: not held
     size_t o_otf, o_cbuf, o_un, o_ra, o_rb, o_hu, o_r1, o_r2, o_w1, o_w2, o_part, o_status,
         o_fftwork;
     Status *status_host = nullptr;  // pinned
@@ -729,6 +730,9 @@ int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], i
     p->o_r2 = take(fb);
     p->o_w1 = take(fb);
     p->o_w2 = take(fb > cb ? fb : cb);  // doubles as the second scratch spectrum of the dual X inverse pass
+    if (p->fc && m3d::fftconv_real_otf_supported(p->fc) &&
+        !(getenv("M3D_RLGC_REAL_OTF2") && atoi(getenv("M3D_RLGC_REAL_OTF2")) == 0))
+        p->o_otf2 = take(cb / 2);
     p->o_part = take(sizeof(KlPartial) * (size_t)(kRowGrid + kMaxGrid) * 2);
     p->o_status = take(sizeof(Status));
     p->o_fftwork = take(p->fft_work ? p->fft_work : 256);
@@ -777,6 +781,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     const Geo g = p->g;
     char *ws = (char *)workspace;
     float2 *otf = (float2 *)(ws + p->o_otf);
+    float *otf2 = p->o_otf2 ? (float *)(ws + p->o_otf2) : nullptr;
     float2 *cbuf = (float2 *)(ws + p->o_cbuf);
     float *un = (float *)(ws + p->o_un);
     float *recon_cur = (float *)(ws + p->o_ra);
@@ -852,11 +857,16 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
                     const m3d::ConvEpilogue *epi = nullptr) -> int {
         ++elog.convolutions;
         if (p->fc)  // every kernel's time is attributed to its pass
-            return m3d::fftconv_conv(p->fc, src, otf, mode, cbuf, dst, st, &elog,
+        {
+            // the consensus convolution (zero-extended input, output read on the core): |OTF|^2 from its float volume
+            const bool real_h = mode == 2 && otf2 && prune && (support & kOutCore) && !(support & kMirrorIn);
+            return m3d::fftconv_conv(p->fc, src, real_h ? (const float2 *)otf2 : otf, real_h ? 3 : mode, cbuf, dst, st,
+                                     &elog,
                                      prune && (support & kInCore) ? &core : nullptr,
                                      prune && (support & kOutCore) ? &core : nullptr,
                                      prune && (support & kMirrorIn) ? &core : nullptr, epi,
                                      fused_tail && (support & kMirrorIn) ? (float2 *)w2 : nullptr);
+        }
         int rc = stamp(m3d::EventLog::kStart);
         if (rc) return rc;
         if ((rc = fft_r2c(src, cbuf))) return rc;
@@ -889,6 +899,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         M3D_KERNEL_CHECK();
         if (p->fc) {
             if ((rc = m3d::fftconv_make_otf(p->fc, hu, otf, st))) return rc;
+            if (otf2 && (rc = m3d::fftconv_otf_abs2(p->fc, otf, otf2, st))) return rc;
         } else if ((rc = fft_r2c(hu, otf))) {
             return rc;
         }

@@ -60,9 +60,9 @@ def main():
         }
     # one Z pass per convolution (the two ratio convolutions share their X inverse pass); the OTF's
     # forward-only Z pass of the first call is counted too
-    # (round 2: the two ratio convolutions share one paired Z launch - the all-planes variant "..., 0, true>" - which
+    # (round 2: the two ratio convolutions share one paired Z launch - the all-planes variant "..., 0, true, ...>" - which
     # therefore counts twice)
-    n_conv = sum(len(v) * (2 if k.endswith("0, true>") else 1) for k, v in fetch.items() if k.startswith("k_z_conv"))
+    n_conv = sum(len(v) * (2 if ", 0, true" in k else 1) for k, v in fetch.items() if k.startswith("k_z_conv"))
     total = 0.0
     for k, v in kernels.items():
         if k.startswith(CONV):
