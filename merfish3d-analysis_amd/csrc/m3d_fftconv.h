@@ -67,7 +67,13 @@ struct ConvEpilogue {
     float *o1, *o2;
     unsigned int *red;  // kRedSlots records of 4 words, kRedStride words apart (128-byte aligned)
     ConvBox core;
+    // kUpdate only, optional: the spectrum the convolution itself runs in.  The X forward transform of the updated
+    // estimate (core rows, symmetric extension along x) is written over the rows just read - the first pass of the next
+    // iteration's forward-model convolution, which then starts at its mirrored Y pass (x_forward_done).  Honoured
+    // where fftconv_update_chain_supported says so; ignored elsewhere.
+    float2 *chain = nullptr;
 };
+bool fftconv_update_chain_supported(const struct FftConvPlan *p);
 // order-preserving map float -> uint32 (atomicMin / atomicMax on floats of either sign)
 __host__ __device__ inline unsigned int float_key(float f)
 {
@@ -90,7 +96,8 @@ __host__ __device__ inline float key_float(unsigned int k)
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                  const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr,
-                 const ConvEpilogue *epilogue = nullptr, float2 *spec_alt = nullptr);
+                 const ConvEpilogue *epilogue = nullptr, float2 *spec_alt = nullptr,
+                 bool x_forward_done = false);  // mirror_box form only: `spec` already holds the core rows' X transforms
 // `mirror_box` (exclusive with in_box): src is only valid inside the box and stands for its
 // symmetric extension to the whole volume (np.pad mode="symmetric", rlgc.py:203-271) - the
 // X pass gathers through the index map instead of reading a materialised pad region.  With a second
@@ -112,7 +119,8 @@ int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *s
 int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                     void *stream, EventLog *log = nullptr, const ConvBox *in_box = nullptr,
                     const ConvBox *out_box = nullptr, const ConvBox *mirror_box = nullptr,
-                    float2 *spec_alt = nullptr, float2 **rows = nullptr);  // *rows: the buffer that holds them
+                    float2 *spec_alt = nullptr, float2 **rows = nullptr,  // *rows: the buffer that holds them
+                    bool x_forward_done = false);
 // The X inverse pass shared by two such results that meet in the consensus arithmetic: the same row of
 // both spectra is one packed complex row (S1 + i S2), one inverse transform returns both real rows and
 // ConvEpilogue::kConsensus runs on them in registers (`a` unused: HT1's numerator is the first result).

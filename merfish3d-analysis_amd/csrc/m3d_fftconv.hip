@@ -828,11 +828,15 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
 }
 
 // Fused tails run on the registers of the last inverse stage: thread t holds x[t + S q] of both packed rows.
-template <int RSET, int EPI, int NS = 0>
+// CHAIN (kUpdate, compile-time geometry): the updated estimate's rows go straight into the X forward transform of the
+// next iteration's forward-model convolution - symmetric extension along x gathered from the row in LDS, the same
+// stages and stores as k_x_forward_reg - written over the spectrum rows this workgroup read (ep.chain == spec).
+template <int RSET, int EPI, int NS = 0, bool CHAIN = false>
 __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restrict__ spec, float *__restrict__ dst,
                                                       ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
+    static_assert(!CHAIN || (EPI == m3d::ConvEpilogue::kUpdate && NS == 2187), "chain: update epilogue, static geometry");
     extern __shared__ float2 lds_ir[];
     __shared__ float smf[8];
     __shared__ unsigned long long smu[4];
@@ -843,8 +847,10 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
     const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    int u1 = 0, u2 = 0;
     if (tid < nb * I) {
-        const int u1 = ax.pos[kp], u2 = ax.pos[kp == 0 ? 0 : S - kp];
+        u1 = ax.pos[kp];
+        u2 = ax.pos[kp == 0 ? 0 : S - kp];
         const int ya = y0 + 2 * pbi;  // rows outside the box were not produced by the Y pass
         const bool va = ya >= g.out.y0 && ya < y_hi, vb = ya + 1 >= g.out.y0 && ya + 1 < y_hi;
         // an invalid row is read from its valid partner (and zeroed below), so both rows lie in one chunk
@@ -889,6 +895,9 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
 #pragma unroll
             for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
             dft9<true>(v);
+            float2 pk[9];  // CHAIN: (new row 2 bi, new row 2 bi + 1) at x = tid + S q; zero outside the core
+#pragma unroll
+            for (int q = 0; q < 9; ++q) pk[q] = make_float2(0.f, 0.f);
             // one output row after the other (tail operands of one row = 18 registers), after the butterflies
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -917,9 +926,59 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
                         updated += (c >= 0.0f) ? 1u : 0u;
                         mx = fmaxf(mx, nw);
                         dmax = fmaxf(dmax, fabsf(nw - old));
+                        if constexpr (CHAIN) {
+                            if (r == 0) pk[q].x = nw;
+                            else pk[q].y = nw;
+                        }
                     }
                 }
             }
+            if constexpr (CHAIN) {  // the slots this thread just read
+                float2 *rw = lds_ir + bi * N + tid;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) rw[S * q] = pk[q];
+            }
+        }
+    }
+    if constexpr (CHAIN) {
+#pragma clang fp contract(fast)
+        __syncthreads();
+        float2 fv[2][9];
+        if (tid < S) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+                    fv[bi][q] = lds_ir[bi * N + sym_src(tid + S * q, g.out.x0, g.out.nx)];
+        }
+        __syncthreads();  // every gather before the first stage overwrites the rows
+        if (tid < S) {
+            float2 w[9];
+            edge_twiddles(w, ax.tw, tid);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                dft9<false>(fv[bi]);
+                float2 *row = lds_ir + bi * N + tid;
+                row[0] = fv[bi][0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q) row[S * q] = cmul(fv[bi][q], w[q]);
+            }
+        }
+        __syncthreads();
+        middle_forward<RSET, NS>(lds_ir, ax, nb, N, tid, nt, g.GX);
+        {
+            float2 c1[9], c2[9];
+            const bool pair_live = tid < nb * I;
+            if (pair_live) forward_pair_load(lds_ir + pbi * N, u1 / 9, u2 / 9, c1, c2);
+            const int64_t zterm = (int64_t)z * g.plane;
+            __syncthreads();  // every pair has read its blocks: the buffer becomes the line staging
+            if (pair_live) forward_pair_emit<true>(c1, c2, g, S, kp, ep.chain, zterm, y0 + 2 * pbi, true, true, lds_ir, 2 * pbi);
+            __syncthreads();
+            unsigned rows_ok = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (y0 + r >= g.out.y0 && y0 + r < y_hi) rows_ok |= 1u << r;
+            store_staged_lines(lds_ir, g, ep.chain, zterm, y0, rows_ok, tid, nt);
         }
     }
     if constexpr (EPI == m3d::ConvEpilogue::kUpdate) {
@@ -1961,7 +2020,7 @@ static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spe
 
 static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spec, hipStream_t st,
                              EventLog *log = nullptr, const ConvBox *in_box = nullptr,
-                             const ConvBox *mirror_box = nullptr, float2 *spec_alt = nullptr)
+                             const ConvBox *mirror_box = nullptr, float2 *spec_alt = nullptr, bool x_done = false)
 {
     if (src && mirror_box && spec_alt && p->TW % 2 == 0) {
         // symmetric extension given by its core: X transforms of the core rows only, the Y pass builds
@@ -1972,7 +2031,7 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         const unsigned yplanes = (unsigned)(p->zmirror ? g.mir.nz : p->Zp);
         const int groups = row_groups(p, g.in);
         if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
-        launch_x_forward(p, src, spec, g, groups, st);
+        if (!x_done) launch_x_forward(p, src, spec, g, groups, st);  // x_done: chained from the update pass
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
         const bool one_reflection = g.mir.y0 <= g.mir.ny && p->Yp - (g.mir.y0 + g.mir.ny) <= g.mir.ny;
         if (p->ystatic && one_reflection)
@@ -2016,12 +2075,13 @@ static bool box_ok(const FftConvPlan *p, const ConvBox *b)
 
 int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                     void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
-                    const ConvBox *mirror_box, float2 *spec_alt, float2 **rows)
+                    const ConvBox *mirror_box, float2 *spec_alt, float2 **rows, bool x_forward_done)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!box_ok(p, in_box) || !box_ok(p, out_box) || !box_ok(p, mirror_box) || (in_box && mirror_box))
         return M3D_ERR_INVALID_ARG;
-    int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box, spec_alt);
+    if (x_forward_done && !(src && mirror_box && spec_alt && p->TW % 2 == 0)) return M3D_ERR_INVALID_ARG;
+    int rc = launch_forward_xy(p, src, spec, st, log, in_box, mirror_box, spec_alt, x_forward_done);
     if (rc) return rc;
     const bool mirrored = src && mirror_box && spec_alt && p->TW % 2 == 0;
     if (mirrored) spec = spec_alt;  // the mirrored Y pass wrote there
@@ -2040,6 +2100,7 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
 }
 
 bool fftconv_real_otf_supported(const FftConvPlan *p) { return p && p->zreg != 0; }
+bool fftconv_update_chain_supported(const FftConvPlan *p) { return p && p->xstatic && p->TW == 4 && p->RB == 4; }
 
 __global__ void k_otf_abs2(const float2 *__restrict__ otf, float *__restrict__ out, int64_t n)
 {
@@ -2123,10 +2184,11 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
 
 int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int mode, float2 *spec,
                  float *dst, void *stream, EventLog *log, const ConvBox *in_box, const ConvBox *out_box,
-                 const ConvBox *mirror_box, const ConvEpilogue *epilogue, float2 *spec_alt)
+                 const ConvBox *mirror_box, const ConvEpilogue *epilogue, float2 *spec_alt, bool x_forward_done)
 {
     hipStream_t st = (hipStream_t)stream;
-    int rc = fftconv_to_rows(p, src, otf, mode, spec, stream, log, in_box, out_box, mirror_box, spec_alt, &spec);
+    int rc = fftconv_to_rows(p, src, otf, mode, spec, stream, log, in_box, out_box, mirror_box, spec_alt, &spec,
+                             x_forward_done);
     if (rc) return rc;
     const ConvGeo g = geo_of(p, in_box, out_box);
     const int groups = row_groups(p, g.out);
@@ -2140,8 +2202,14 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
     hipLaunchKernelGGL((k_x_inverse<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
 #define M3D_LAUNCH_XIR(RS, EP) \
     hipLaunchKernelGGL((k_x_inverse_reg<RS, EP>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep)
+    if (ep.chain && !(ep.kind == ConvEpilogue::kUpdate && fftconv_update_chain_supported(p) && ep.chain == spec &&
+                      out_box && ep.core.z0 == out_box->z0 && ep.core.nz == out_box->nz && ep.core.y0 == out_box->y0 &&
+                      ep.core.ny == out_box->ny && ep.core.x0 == out_box->x0 && ep.core.nx == out_box->nx))
+        return M3D_ERR_INVALID_ARG;
     if (p->xstatic && ep.kind != ConvEpilogue::kConsensus) {
-        if (ep.kind == ConvEpilogue::kUpdate)
+        if (ep.kind == ConvEpilogue::kUpdate && ep.chain)
+            hipLaunchKernelGGL((k_x_inverse_reg<1, 2, 2187, true>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+        else if (ep.kind == ConvEpilogue::kUpdate)
             hipLaunchKernelGGL((k_x_inverse_reg<1, 2, 2187>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
         else
             hipLaunchKernelGGL((k_x_inverse_reg<1, 0, 2187>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);

@@ -854,7 +854,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     const bool fused_tail = p->fc && prune;
     unsigned int *cons_red = (unsigned int *)mm_part, *upd_red = (unsigned int *)up_part;
     auto conv = [&](float *src, int mode, float *dst, int support = kFull,
-                    const m3d::ConvEpilogue *epi = nullptr) -> int {
+                    const m3d::ConvEpilogue *epi = nullptr, bool x_forward_done = false) -> int {
         ++elog.convolutions;
         if (p->fc)  // every kernel's time is attributed to its pass
         {
@@ -865,7 +865,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
                                      prune && (support & kInCore) ? &core : nullptr,
                                      prune && (support & kOutCore) ? &core : nullptr,
                                      prune && (support & kMirrorIn) ? &core : nullptr, epi,
-                                     fused_tail && (support & kMirrorIn) ? (float2 *)w2 : nullptr);
+                                     fused_tail && (support & kMirrorIn) ? (float2 *)w2 : nullptr, x_forward_done);
         }
         int rc = stamp(m3d::EventLog::kStart);
         if (rc) return rc;
@@ -931,8 +931,13 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     M3D_HIP_CHECK(hipMemsetAsync(r1, 0, sizeof(float) * (size_t)g.Np, st));
     M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
 
+    // The update pass can hand the next forward-model convolution its X forward transform (ConvEpilogue::chain).
+    const bool chain_update = fused_tail && m3d::fftconv_update_chain_supported(p->fc) &&
+                              !(getenv("M3D_RLGC_CHAIN_UPDATE") && atoi(getenv("M3D_RLGC_CHAIN_UPDATE")) == 0);
+    bool hu_x_ready = false;  // cbuf holds the X transforms of recon_cur's core rows
     auto enqueue_forward = [&](int it) -> int {
-        int rc2 = conv(recon_cur, 0, hu, kOutCore | kMirrorIn);  // Hu, rlgc.py:624 (read on the core only)
+        int rc2 = conv(recon_cur, 0, hu, kOutCore | kMirrorIn, nullptr, hu_x_ready);  // Hu, rlgc.py:624 (core only)
+        hu_x_ready = false;
         if (rc2) return rc2;
         const float *inj =
             (injected && it < n_injected) ? injected + (size_t)it * (size_t)g.N : nullptr;
@@ -970,9 +975,10 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             const bool chain = !(getenv("M3D_RLGC_NO_CHAIN") && atoi(getenv("M3D_RLGC_NO_CHAIN")));
             const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, nullptr, un, hu, w1, cons_red, core};
             if ((rc2 = m3d::fftconv_dual_consensus(p->fc, cbuf, cbuf2, st, &elog, &e1, chain))) return rc2;
-            const m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr,
-                                          upd_red, core};
+            m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr, upd_red, core};
+            if (chain_update) e2.chain = cbuf;
             if ((rc2 = conv(chain ? nullptr : hu, 2, w2, kOutCore, &e2))) return rc2;
+            hu_x_ready = chain_update;
             hipLaunchKernelGGL(k_fused_finalize, dim3(1), dim3(kBlock), 0, st, cons_red, upd_red, dstat);
             M3D_KERNEL_CHECK();
             return M3D_OK;
