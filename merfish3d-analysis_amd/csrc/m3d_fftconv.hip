@@ -1229,11 +1229,14 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
 template <int R, bool INV, int N, int M, int TWc, int NT_>
 __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__restrict__ tw, int tid)
 {
-    // four interleaved transforms per butterfly item (G = TW = 4): element k of transform b at data[k * TW + b]
+    // four interleaved transforms (TW = 4): element k of transform b at data[k * TW + b]
     constexpr int sub = M / R, per_fft = N / R, twstep = N / M, step = sub * TWc;
+    // one (butterfly, column) pair per work item: four times the parallelism for the price of recomputing the twiddles
+    // per column (the pass waits on LDS latency, 71 % of wave time, not on instruction issue)
 #pragma unroll 1
-    for (int t = tid; t < per_fft; t += NT_) {
-        const int blk = t / sub, j = t - blk * sub;
+    for (int t = tid; t < per_fft * TWc; t += NT_) {
+        const int c = t & (TWc - 1), it = t / TWc;
+        const int blk = it / sub, j = it - blk * sub;
         float2 w[R];
         const int j1 = j * twstep;
         if constexpr (R == 9) {
@@ -1250,26 +1253,21 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
             if constexpr (R >= 3) w[2] = cmul(w[1], w[1]);
             if constexpr (R >= 4) w[3] = cmul(w[1], w[2]);
         }
-        float2 *p0 = data + (blk * M + j) * TWc;
-        const int rot = t >> 3;  // lanes 8 apart sit 256 B apart: rotate the member each lane starts with
+        float2 *p = data + (blk * M + j) * TWc + c;
+        float2 v[R];
 #pragma unroll
-        for (int it = 0; it < TWc; ++it) {
-            float2 *p = p0 + ((it + rot) & (TWc - 1));
-            float2 v[R];
+        for (int q = 0; q < R; ++q) v[q] = p[q * step];
+        if (INV) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) v[q] = p[q * step];
-            if (INV) {
+            for (int q = 1; q < R; ++q) v[q] = cmul_conj(v[q], w[q]);
+            dft_r<R, true>(v);
+        } else {
+            dft_r<R, false>(v);
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmul_conj(v[q], w[q]);
-                dft_r<R, true>(v);
-            } else {
-                dft_r<R, false>(v);
-#pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < R; ++q) p[q * step] = v[q];
+            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
         }
+#pragma unroll
+        for (int q = 0; q < R; ++q) p[q * step] = v[q];
     }
 }
 
@@ -1820,9 +1818,12 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
                p->ax.radix[p->ax.nstages - 1] == 9 && p->xthreads == 256 && p->dual_threads == 256 &&
                p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 256 && Xp / 9 <= 256)
                   ? 1 : 0;
-    p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && p->ythreads == 768 &&
+    p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && (p->ythreads == 768 || p->ythreads == 1024) &&
                   p->gy == 4 && p->ay.nstages == 4 && p->ay.radix[0] == 9 && p->ay.radix[1] == 9 &&
                   p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 1 : 0;
+    // the static Y kernels spread (butterfly, column) pairs over the threads: 972 pairs in the radix-9 stages, one
+    // round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
+    if (p->ystatic && getenv("M3D_FFT_YT") == nullptr) p->ythreads = 1024;
     p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
                   p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&
                   p->ax.radix[2] == 3) ? 1 : 0;
@@ -1898,6 +1899,9 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 1024>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 1024>, attr, (int)p->lds_y);
+    (void)hipFuncSetAttribute((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 1024>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
     (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
@@ -1994,7 +1998,10 @@ static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, 
 {
     const dim3 grid((unsigned)(nz * p->nT)), block(p->ythreads);
     if (p->ystatic) {
-        hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 768>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+        if (p->ythreads == 1024)
+            hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+        else
+            hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 768>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     } else if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<INV, 1>), grid, block, p->lds_y, st, spec, g, p->ay);
     else
@@ -2034,7 +2041,10 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         if (!x_done) launch_x_forward(p, src, spec, g, groups, st);  // x_done: chained from the update pass
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
         const bool one_reflection = g.mir.y0 <= g.mir.ny && p->Yp - (g.mir.y0 + g.mir.ny) <= g.mir.ny;
-        if (p->ystatic && one_reflection)
+        if (p->ystatic && one_reflection && p->ythreads == 1024)
+            hipLaunchKernelGGL((k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 1024>), dim3(yplanes * (unsigned)p->nT),
+                               dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);
+        else if (p->ystatic && one_reflection)
             hipLaunchKernelGGL((k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>), dim3(yplanes * (unsigned)p->nT),
                                dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);
         else if (p->rset_y)
