@@ -972,13 +972,16 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
             if (pair_live) forward_pair_load(lds_ir + pbi * N, u1 / 9, u2 / 9, c1, c2);
             const int64_t zterm = (int64_t)z * g.plane;
             __syncthreads();  // every pair has read its blocks: the buffer becomes the line staging
-            if (pair_live) forward_pair_emit<true>(c1, c2, g, S, kp, ep.chain, zterm, y0 + 2 * pbi, true, true, lds_ir, 2 * pbi);
+            // ep.chain == spec (checked by the host): store through a pointer derived from `spec` itself, so that the
+            // restrict qualifier of the read pointer stays honest
+            float2 *chain = const_cast<float2 *>(spec);
+            if (pair_live) forward_pair_emit<true>(c1, c2, g, S, kp, chain, zterm, y0 + 2 * pbi, true, true, lds_ir, 2 * pbi);
             __syncthreads();
             unsigned rows_ok = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (y0 + r >= g.out.y0 && y0 + r < y_hi) rows_ok |= 1u << r;
-            store_staged_lines(lds_ir, g, ep.chain, zterm, y0, rows_ok, tid, nt);
+            store_staged_lines(lds_ir, g, chain, zterm, y0, rows_ok, tid, nt);
         }
     }
     if constexpr (EPI == m3d::ConvEpilogue::kUpdate) {
