@@ -241,9 +241,16 @@ def pmc_traffic(padded_shape, key="rlgc_iteration_hbm_bytes"):
     return None
 
 
+def _process_group_live() -> bool:
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
 def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tuple[float, float]:
-    """(max elapsed over ranks, total RLGC iterations over ranks) - the bench contract's timing rule."""
-    if world <= 1:
+    """(max elapsed over ranks, total RLGC iterations over ranks) - the bench contract's timing rule.  A live
+    process group is used whatever its size (a one-rank RCCL group is how a one-GPU box rehearses this)."""
+    if world <= 1 and not _process_group_live():
         return float(elapsed), float(iters)
     import torch.distributed as dist
 
@@ -258,7 +265,7 @@ def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tu
 
 def agree_min(value: int, world: int, device) -> int:
     """The same integer on every rank: the minimum of the ranks' proposals (step counts must agree)."""
-    if world <= 1:
+    if world <= 1 and not _process_group_live():
         return int(value)
     import torch.distributed as dist
 
@@ -384,9 +391,17 @@ def main() -> int:
     gpu_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(gpu_index)
     device = torch.device("cuda", gpu_index)
-    if world > 1:
+    # M3D_BENCH_FORCE_DIST=1: a one-rank run still joins an RCCL process group, so the barrier and the
+    # all-reduces of the N > 1 path execute on a one-GPU box (tests/test_gpu_rccl_single_rank.py)
+    force_dist = world == 1 and os.environ.get("M3D_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -542,7 +557,7 @@ def main() -> int:
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
 
             dist.barrier()
@@ -683,6 +698,12 @@ def main() -> int:
                 truth[:, 1:4].astype(float), truth[:, 0], 3.0)[0]
             out["f1_vs_planted_emitters"] = {k: (round(v, 4) if isinstance(v, float) else int(v)) for k, v in f1.items()}
         out.update(extras)
+        if _process_group_live():
+            import torch.distributed as dist
+
+            out["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        if world > 1:
+            out["omitted_at_n_gt_1"] = ["cpu_baseline", "roofline_decode", "io"]   # rank-0, N = 1 legs only
         if "io" in out:
             io = dict(out["io"])
             step_s = elapsed / max(tiles_done, 1)
@@ -772,7 +793,7 @@ def main() -> int:
         if stop and i + 1 < n_steps:
             progress(f"stopping after {steps_done} timed step(s): wall budget")
             break
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         dist.destroy_process_group()

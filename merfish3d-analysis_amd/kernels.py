@@ -8,6 +8,8 @@ already live in HBM and enqueues on the current torch stream.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -349,10 +351,15 @@ class PooledValues:
 
 
 def _dist_ready() -> bool:
+    """True when the job runs one process per GPU under ``torch.distributed``.  A process group of ONE rank
+    counts only with ``M3D_DIST_SINGLE_RANK=1``: that is how a one-GPU box drives the RCCL code path
+    (device histogram -> ``all_reduce``) that the multi-GPU run takes."""
     try:
         import torch.distributed as dist
 
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or os.environ.get("M3D_DIST_SINGLE_RANK") == "1"
     except Exception:
         return False
 
