@@ -42,3 +42,28 @@ def store_from_stack(stack_list, codebook_df, voxel=(0.315, 0.098, 0.098), micro
 def sort_table(df: pd.DataFrame) -> pd.DataFrame:
     cols = ["tile_z", "tile_y", "tile_x", "gene_id", "area"]
     return df.sort_values(cols, kind="stable").reset_index(drop=True)
+
+
+def use_scipy_lowpass(monkeypatch):
+    """Replace the package's Gaussian low-pass by SciPy's (float64 accumulation) for one test: that is what the
+    reference run behind the fixtures used (cupyx.scipy.ndimage stand-in), so everything downstream of the low-pass
+    can be asserted exactly instead of to the float32-vs-float64 rounding of the filter.  The HIP low-pass itself is
+    compared with SciPy in tests/test_gpu_decode.py."""
+    import scipy.ndimage as sndi
+    import torch
+
+    kernels = pkg("kernels")
+
+    def lowpass(volume, sigma_zyx, is_3d=True, out=None, scratch=None):
+        img = volume.detach().cpu().numpy().astype(np.float32)
+        if is_3d:
+            res = sndi.gaussian_filter(img, sigma=tuple(float(v) for v in sigma_zyx))
+        else:
+            res = np.stack([sndi.gaussian_filter(p, sigma=(float(sigma_zyx[1]), float(sigma_zyx[2]))) for p in img])
+        t = torch.from_numpy(np.ascontiguousarray(res, dtype=np.float32)).to(volume.device)
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
+
+    monkeypatch.setattr(kernels, "gaussian_lowpass", lowpass)

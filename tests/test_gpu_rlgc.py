@@ -1,9 +1,9 @@
 """GPU parity: HIP RLGC (through the C ABI) against the NumPy oracle.
 
-Tolerances: rocFFT and pocketfft differ at float32 rounding (~1e-7 per transform) and
-RLGC multiplies ~25-40 updates together, so volumes are compared at 2e-3 of the peak
-(north_star: floats within tolerance, integers exact); iteration counts, stop reasons and
-the Philox split are compared exactly.
+Tolerances: the in-LDS transforms and pocketfft differ at float32 rounding (~1e-7 per transform)
+and RLGC multiplies ~25-80 updates together; measured differences are 3e-6 of the peak, the
+tests allow 1e-4 (north_star: float distances within 1e-4, integers exact); iteration counts,
+stop reasons and the Philox split are compared exactly.
 """
 
 import warnings
@@ -17,6 +17,9 @@ from oracle import philox, rlgc_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+
+VOLUME_TOL = 1e-4   # of the volume's peak
 
 
 def _rel_err(a, b):
@@ -49,10 +52,10 @@ def test_rlgc_matches_oracle_with_philox_split(golden, name):
     assert out.dtype == np.float32 and out.shape == g["image"].shape
     assert info.padded_shape == rinfo.padded_shape
     assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
-    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=2e-3, atol=1e-6)
-    np.testing.assert_allclose(info.kld_split2, rinfo.kld_split2, rtol=2e-3, atol=1e-6)
-    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=2e-3)
-    assert _rel_err(out, ref) < 2e-3
+    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.kld_split2, rinfo.kld_split2, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=1e-4)
+    assert _rel_err(out, ref) < VOLUME_TOL
     # same result when the image arrives as float32 or already sits in HBM
     out_f, _ = rl.rlgc(g["image"].astype(np.float32), g["psf"], return_info=True, release_memory=False)
     assert np.array_equal(out_f, out)
@@ -76,7 +79,7 @@ def test_rlgc_matches_reference_golden_with_injected_reference_splits(golden):
     out, info = rl.rlgc_device(torch.from_numpy(g["image"]).to(DEV), torch.from_numpy(g["psf"]).to(DEV),
                                injected_splits=torch.from_numpy(splits).to(DEV))
     assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
-    assert _rel_err(out.cpu().numpy(), g["output"]) < 2e-3
+    assert _rel_err(out.cpu().numpy(), g["output"]) < VOLUME_TOL
 
 
 def test_rlgc_tiled_route_and_2d_input(golden):
@@ -87,13 +90,13 @@ def test_rlgc_tiled_route_and_2d_input(golden):
         ref = rlgc_ref.chunked_rlgc(g["image"], g["psf"], crop_yx=int(g["crop_yx"]),
                                     rng_seed=int(g["rng_seed"]), rng="philox")
     out = rl.chunked_rlgc(g["image"], g["psf"], crop_yx=int(g["crop_yx"]), rng_seed=int(g["rng_seed"]))
-    assert out.shape == ref.shape and _rel_err(out, ref) < 5e-3
+    assert out.shape == ref.shape and _rel_err(out, ref) < VOLUME_TOL
     g2 = golden("rlgc_2d")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         ref2 = rlgc_ref.chunked_rlgc(g2["image"], g2["psf"], rng="philox")
     out2 = rl.chunked_rlgc(g2["image"], g2["psf"])
-    assert out2.shape == g2["image"].shape and _rel_err(out2, ref2) < 5e-3
+    assert out2.shape == g2["image"].shape and _rel_err(out2, ref2) < VOLUME_TOL
 
 
 def _phantom(shape, psf_shape, sigma, n_spots, seed):
@@ -127,9 +130,9 @@ def test_solver_with_register_z_pass_matches_oracle(shape, psf_shape, padded):
     out, info = rl.rlgc(img, psf, gpu_id=0, return_info=True, release_memory=False)
     assert tuple(info.padded_shape) == padded
     assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
-    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=2e-3, atol=1e-6)
-    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=2e-3)
-    assert _rel_err(out, ref) < 2e-3
+    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=1e-4)
+    assert _rel_err(out, ref) < VOLUME_TOL
     # what DataRegistration stores: clip -> uint16 (truncation).  FFT rounding moves a value across an integer in a
     # small fraction of voxels, never by more than one count
     a, b = np.clip(out, 0, 65535).astype(np.uint16).astype(np.int64), np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64)
