@@ -149,6 +149,20 @@ int m3d_fftconv_apply(m3d_fftconv *handle, const float *image, const void *otf, 
 int m3d_rlgc_debug_split(const void *image, int image_dtype, int64_t n, uint64_t seed,
                          int32_t iteration, float *split1, void *stream);
 
+/* The split sampler's tables as the library built them (host memory, valid for the life of the process; no GPU
+   call): thresholds floor(2^63 P(|X - 32 q| <= i)) of X ~ Binomial(64 q, 1/2); row q (2 <= q <= *q_max) is given as an
+   (offset, length) pair, rows have one stride (n_thresholds / (q_max + 1)) and sit between sentinels:
+   thresholds[offset] = 0, thresholds[offset + 1 + i] = threshold i, 2^64 - 1 from offset + 1 + length to the end of
+   the row.  For the parity test against the oracle's exact integers
+   (the sampler replaces the binomial draw of rlgc.py:564, 619-622). */
+int m3d_binom_tables_host(const uint64_t **thresholds, int64_t *n_thresholds, const uint32_t **row_off_len,
+                          int32_t *q_max);
+
+/* Binomial(64 q[i], 1/2) by table inversion of the 64-bit uniforms (hi[i]:lo[i]) on the device, 2 <= q[i] <= q_max:
+   lets the parity tests place draws on and next to every threshold. */
+int m3d_binom_debug_table_draw(const uint32_t *q, const uint32_t *hi, const uint32_t *lo, int64_t n, uint32_t *out,
+                               void *stream);
+
 /* clip(0, 65535).astype(uint16) of RLGC output, DataRegistration.py:435, 993-995 */
 int m3d_clip_to_u16(const float *in, uint16_t *out, int64_t n, void *stream);
 

@@ -1,12 +1,10 @@
-// Counter-based Binomial(n, 1/2) photon split: Philox4x32 (kSplitRounds rounds) + pop-count.
-//
-// Replaces cp.random.default_rng(seed).binomial(n, 0.5) of the reference
-// (utils/rlgc.py:564, 619-622).  Stateless, so the split is regenerated wherever it is
-// needed instead of being stored (saves two full-volume passes per iteration), exact in
-// distribution, integer only - bit-identical to oracle/philox.py.
+// Philox4x32 (kSplitRounds rounds): the counter-based generator under the Binomial(n, 1/2) photon split of
+// m3d_binom.h, which replaces cp.random.default_rng(seed).binomial(n, 0.5) of the reference
+// (utils/rlgc.py:564, 619-622).  Stateless, so the split is regenerated wherever it is needed instead of being
+// stored (saves two full-volume passes per iteration); integer only - bit-identical to oracle/philox.py.
 //
 //   key     = (seed lo, seed hi)
-//   counter = (voxel lo, voxel hi, iteration, chunk);  each block yields 128 bits
+//   counter = (voxel lo, voxel hi, iteration, block);  each block yields 128 bits
 #pragma once
 #include <stdint.h>
 
@@ -62,31 +60,6 @@ M3D_HD int popc32(uint32_t v)
 M3D_HD uint32_t low_mask(int nbits)  // nbits in [0, 32]
 {
     return nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
-}
-
-// Exact Binomial(n, 1/2) for voxel `voxel` at `iteration`.
-M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, uint64_t seed)
-{
-    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t acc = 0;
-    uint32_t chunk = 0;
-    int64_t rem = (int64_t)n;
-    while (rem > 0) {
-        U32x4 c = {(uint32_t)voxel, (uint32_t)(voxel >> 32), iteration, chunk};
-        const U32x4 r = philox4x32<kSplitRounds>(c, k0, k1);
-        if (rem >= 128) {
-            acc += popc32(r.x) + popc32(r.y) + popc32(r.z) + popc32(r.w);
-        } else {
-            const int q = (int)rem;
-            acc += popc32(r.x & low_mask(q > 32 ? 32 : q));
-            acc += popc32(r.y & low_mask(q - 32 < 0 ? 0 : (q - 32 > 32 ? 32 : q - 32)));
-            acc += popc32(r.z & low_mask(q - 64 < 0 ? 0 : (q - 64 > 32 ? 32 : q - 64)));
-            acc += popc32(r.w & low_mask(q - 96 < 0 ? 0 : (q - 96 > 32 ? 32 : q - 96)));
-        }
-        rem -= 128;
-        ++chunk;
-    }
-    return acc;
 }
 
 }  // namespace m3d

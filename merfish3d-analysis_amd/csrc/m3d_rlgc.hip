@@ -33,12 +33,14 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "m3d_common.h"
 #include "m3d_fftconv.h"
 #include "m3d_index.h"
+#include "m3d_binom.h"
 #include "m3d_philox.h"
 
 using namespace m3d;
@@ -210,7 +212,7 @@ __global__ void k_cmul(float2 *__restrict__ x, const float2 *__restrict__ h, int
 template <typename T>
 __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict__ image,
                               float *__restrict__ r1, float *__restrict__ r2, Geo g,
-                              uint32_t iteration, uint64_t seed,
+                              uint32_t iteration, uint64_t seed, BinomTables tables,
                               const float *__restrict__ injected, KlPartial *__restrict__ partial)
 {
     __shared__ double sm[4];
@@ -249,9 +251,10 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
                 } else {
                     const float vt = v > 0.0f ? v : 0.0f;
                     // astype(int64) truncation, rlgc.py:619; counts above 2^20 are clamped for
-                    // the draw only (bounds the loop; u16 data never reaches it)
+                    // the draw only (bounds the chunk loop; u16 data never reaches it)
                     const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);
-                    s1 = (float)binomial_half(n, (uint64_t)(irow + x), iteration, seed);
+                    // a uint16 count needs one Philox block and one table row at most
+                    s1 = (float)binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + x), iteration, seed, tables);
                 }
                 const float s2 = v - s1;
                 // kl_div, rlgc.py:401-412, as raw sums (normalisers applied on the host)
@@ -515,15 +518,24 @@ __global__ void k_crop(const float *__restrict__ recon, float *__restrict__ out,
 
 template <typename T>
 __global__ void k_debug_split(const T *__restrict__ image, int64_t n, uint64_t seed,
-                              uint32_t iteration, float *__restrict__ split1)
+                              uint32_t iteration, BinomTables tables, float *__restrict__ split1)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const float v = load_as_f32(image, i);
         const float vt = v > 0.0f ? v : 0.0f;
-        split1[i] =
-            (float)binomial_half((uint32_t)fminf(vt, 1048576.0f), (uint64_t)i, iteration, seed);
+        split1[i] = (float)binomial_half<!(sizeof(T) == 2)>((uint32_t)fminf(vt, 1048576.0f), (uint64_t)i, iteration,
+                                                            seed, tables);
     }
+}
+
+__global__ void k_debug_table_draw(const uint32_t *__restrict__ q, const uint32_t *__restrict__ hi,
+                                   const uint32_t *__restrict__ lo, int64_t n, BinomTables tables,
+                                   uint32_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = binom_table_draw(q[i], hi[i], lo[i], tables);
 }
 
 __global__ void k_clip_u16(const float *__restrict__ in, uint16_t *__restrict__ out, int64_t n)
@@ -537,6 +549,33 @@ __global__ void k_clip_u16(const float *__restrict__ in, uint16_t *__restrict__ 
 }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// The split sampler's threshold / guide tables (m3d_binom.h): built once per process, one copy per device.
+int device_binom_tables(BinomTables *out)
+{
+    static std::mutex mu;
+    static BinomTables per_device[64] = {};
+    int dev = 0;
+    M3D_HIP_CHECK(hipGetDevice(&dev));
+    M3D_REQUIRE(dev >= 0 && dev < 64, "device index");
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[dev].thr) {
+        const BinomTablesHost &h = binom_tables_host();
+        if (!h.certified) {
+            set_err("binomial split tables", "a threshold could not be certified");
+            return M3D_ERR_HIP;
+        }
+        uint64_t *thr = nullptr;
+        BinomRow *rows = nullptr;
+        M3D_HIP_CHECK(hipMalloc(&thr, h.thr.size() * sizeof(uint64_t)));
+        M3D_HIP_CHECK(hipMalloc(&rows, h.rows.size() * sizeof(BinomRow)));
+        M3D_HIP_CHECK(hipMemcpy(thr, h.thr.data(), h.thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        M3D_HIP_CHECK(hipMemcpy(rows, h.rows.data(), h.rows.size() * sizeof(BinomRow), hipMemcpyHostToDevice));
+        per_device[dev] = BinomTables{thr, rows};
+    }
+    *out = per_device[dev];
+    return M3D_OK;
+}
 
 }  // namespace
 
@@ -778,6 +817,8 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         return M3D_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream_v;
+    BinomTables binom;
+    if (int rc_tables = device_binom_tables(&binom)) return rc_tables;
     const Geo g = p->g;
     char *ws = (char *)workspace;
     float2 *otf = (float2 *)(ws + p->o_otf);
@@ -944,11 +985,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         if (image_dtype == M3D_U16)
             hipLaunchKernelGGL(k_split_ratio<uint16_t>, dim3(g_core), rb, 0, st, hu,
                                (const uint16_t *)image, r1, r2, g, (uint32_t)it, params->seed,
-                               inj, kl_part);
+                               binom, inj, kl_part);
         else
             hipLaunchKernelGGL(k_split_ratio<float>, dim3(g_core), rb, 0, st, hu,
-                               (const float *)image, r1, r2, g, (uint32_t)it, params->seed, inj,
-                               kl_part);
+                               (const float *)image, r1, r2, g, (uint32_t)it, params->seed, binom,
+                               inj, kl_part);
         hipLaunchKernelGGL(k_kl_finalize, dim3(1), dim3(kBlock), 0, st, kl_part, g_core, dstat);
         M3D_KERNEL_CHECK();
         return M3D_OK;
@@ -1103,15 +1144,46 @@ int m3d_rlgc_debug_split(const void *image, int image_dtype, int64_t n, uint64_t
     M3D_REQUIRE(image && split1 && n >= 0, "null pointer");
     hipStream_t st = (hipStream_t)stream_v;
     if (n == 0) return M3D_OK;
+    BinomTables binom;
+    if (int rc = device_binom_tables(&binom)) return rc;
     if (image_dtype == M3D_U16)
         hipLaunchKernelGGL(k_debug_split<uint16_t>, dim3(grid_for(n)), dim3(kBlock), 0, st,
-                           (const uint16_t *)image, n, seed, (uint32_t)iteration, split1);
+                           (const uint16_t *)image, n, seed, (uint32_t)iteration, binom, split1);
     else if (image_dtype == M3D_F32)
         hipLaunchKernelGGL(k_debug_split<float>, dim3(grid_for(n)), dim3(kBlock), 0, st,
-                           (const float *)image, n, seed, (uint32_t)iteration, split1);
+                           (const float *)image, n, seed, (uint32_t)iteration, binom, split1);
     else
         M3D_REQUIRE(false, "image dtype must be u16 or f32");
     M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int m3d_binom_debug_table_draw(const uint32_t *q, const uint32_t *hi, const uint32_t *lo, int64_t n, uint32_t *out,
+                               void *stream_v)
+{
+    M3D_REQUIRE(q && hi && lo && out && n >= 0, "null pointer");
+    if (n == 0) return M3D_OK;
+    BinomTables binom;
+    if (int rc = device_binom_tables(&binom)) return rc;
+    hipLaunchKernelGGL(k_debug_table_draw, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream_v, q, hi, lo, n,
+                       binom, out);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+int m3d_binom_tables_host(const uint64_t **thresholds, int64_t *n_thresholds, const uint32_t **row_off_len,
+                          int32_t *q_max)
+{
+    const BinomTablesHost &h = binom_tables_host();
+    if (!h.certified) {
+        set_err("binomial split tables", "a threshold could not be certified");
+        return M3D_ERR_HIP;
+    }
+    static_assert(sizeof(BinomRow) == 2 * sizeof(uint32_t), "rows are (offset, length) pairs");
+    if (thresholds) *thresholds = h.thr.data();
+    if (n_thresholds) *n_thresholds = (int64_t)h.thr.size();
+    if (row_off_len) *row_off_len = (const uint32_t *)h.rows.data();
+    if (q_max) *q_max = (int32_t)kBinomQMax;
     return M3D_OK;
 }
 

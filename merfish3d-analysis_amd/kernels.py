@@ -138,6 +138,18 @@ def rlgc_debug_split(image: torch.Tensor, seed: int, iteration: int) -> torch.Te
     return out
 
 
+def binom_debug_table_draw(q: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    """Binomial(64 q, 1/2) by table inversion of the 64-bit uniforms (hi:lo) on the device (parity hook)."""
+    q, hi, lo = (t.contiguous() for t in (q, hi, lo))
+    if not (q.dtype == hi.dtype == lo.dtype == torch.uint32) or not (q.shape == hi.shape == lo.shape):
+        raise ValueError("q, hi, lo must be uint32 tensors of one shape")
+    out = torch.empty(q.shape, dtype=torch.uint32, device=q.device)
+    with torch.cuda.device(q.device):
+        _hip.check(_hip.lib().m3d_binom_debug_table_draw(q.data_ptr(), hi.data_ptr(), lo.data_ptr(), q.numel(),
+                                                         out.data_ptr(), _stream(q)), "m3d_binom_debug_table_draw")
+    return out
+
+
 SUM_COLS = 11  # area, sz, sy, sx, szz, syy, sxx, szy, szx, syx, magnitude sum (+ B intensity sums)
 
 

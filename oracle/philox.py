@@ -5,16 +5,22 @@ ORACLE / TEST INFRASTRUCTURE ONLY - see ``oracle/__init__.py``.
 The reference draws the RLGC 50:50 split with
 ``cp.random.default_rng(seed).binomial(n, 0.5)`` (``utils/rlgc.py:564,619-622``),
 a cuRAND stream nothing else can reproduce.  The MI355X build replaces it by a
-stateless sampler that needs no stored split array: for voxel ``v`` at
-iteration ``it`` the split is the pop-count of ``n`` fresh random bits taken
-from Philox4x32 blocks (``SPLIT_ROUNDS`` = 7 rounds) with
+stateless sampler that needs no stored split array and ONE Philox4x32 block
+(``SPLIT_ROUNDS`` = 7 rounds) per voxel whatever the count:
 
     key     = (seed & 0xffffffff, seed >> 32)
-    counter = (v & 0xffffffff, v >> 32, it, chunk)      chunk = 0, 1, ...
+    counter = (v & 0xffffffff, v >> 32, it, block)      block = 0 (1, 2, ... only above 65535 counts)
+    n = 64 q + r
+    r < 64  pop-count of r bits of words (x, y)                                  exact
+    q = 1   pop-count of words (z, w)                                            exact
+    q >= 2  inversion of the 64-bit uniform (z:w): lowest bit = sign, X = 32 q +- D where D is the number of
+            thresholds floor(2^63 P(|X - 32 q| <= i)) that are <= the upper 63 bits
+    q > 1023: chunks of 64 * 1023, one more 64-bit uniform each ((x:y), (z:w) of blocks 1, 2, ...)
 
-each block supplying 128 bits.  This is an *exact* Binomial(n, 1/2) draw, purely
-integer, hence bit-identical between this file and
-``merfish3d-analysis_amd/csrc/m3d_philox.h``.
+The thresholds are exact integers: ``binomial_row`` evaluates them in 191-bit fixed point with floor divisions,
+carries the truncation-error bound and accepts a threshold only when both ends of its error interval floor to the same
+integer.  ``merfish3d-analysis_amd/csrc/m3d_binom.h`` certifies its own tables the same way; both are purely integer,
+hence bit-identical.
 """
 
 from __future__ import annotations
@@ -65,6 +71,69 @@ def _popcount32(x: np.ndarray) -> np.ndarray:
     return ((x * np.uint32(0x01010101)) >> np.uint32(24)).astype(np.int64)
 
 
+Q_MAX = 1023
+_P = 191          # fixed-point fraction bits; thresholds = sum >> 128
+_V_MAX = (1 << 63) - 1
+_central_cache: dict[int, int] = {}
+_row_cache: dict[int, np.ndarray] = {}
+
+
+def _central_terms() -> dict[int, int]:
+    """floor-chain of C(2m, m) / 4^m * 2^191 at m = 32 q (truncation error < m units)."""
+    if not _central_cache:
+        c = 1 << _P
+        k = 0
+        for q in range(1, Q_MAX + 1):
+            m = 32 * q
+            while k < m:
+                k += 1
+                c = c * (2 * k - 1) // (2 * k)
+            _central_cache[q] = c
+    return _central_cache
+
+
+def binomial_row(q: int) -> np.ndarray:
+    """Thresholds T[i] = floor(2^63 P(|X - 32 q| <= i)), X ~ Binomial(64 q, 1/2), for all i with T[i] < 2^63 - 1."""
+    q = int(q)
+    if q in _row_cache:
+        return _row_cache[q]
+    if not 2 <= q <= Q_MAX:
+        raise ValueError("rows exist for 2 <= q <= 1023")
+    m = 32 * q
+    term = total = _central_terms()[q]
+    err = m
+    rows = []
+    i = 0
+    while True:
+        if i > 0:
+            term = term * (m - i + 1) // (m + i)
+            total += 2 * term
+            err += 2 * (m + i)
+        lo = total >> 128
+        if lo >= _V_MAX or i >= m:
+            break
+        if (total + err) >> 128 != lo:
+            raise ArithmeticError(f"threshold {i} of row {q} not certified")
+        rows.append(lo)
+        i += 1
+    out = np.asarray(rows, dtype=np.uint64)
+    _row_cache[q] = out
+    return out
+
+
+def _table_draw(q: np.ndarray, hi: np.ndarray, lo: np.ndarray) -> np.ndarray:
+    """Binomial(64 q, 1/2) for 2 <= q <= Q_MAX from the 64-bit uniforms (hi:lo)."""
+    u = (hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)
+    v = u >> np.uint64(1)
+    sign = (u & np.uint64(1)).astype(np.int64)
+    out = np.zeros(q.shape, dtype=np.int64)
+    for qq in np.unique(q):
+        sel = np.nonzero(q == qq)[0]
+        d = np.searchsorted(binomial_row(int(qq)), v[sel], side="right").astype(np.int64)
+        out[sel] = 32 * int(qq) + np.where(sign[sel] == 1, d, -d)
+    return out
+
+
 def binomial_half(n: np.ndarray, voxel_index: np.ndarray, iteration: int, seed: int):
     """Exact Binomial(n, 1/2) per voxel; ``n`` int64 >= 0, ``voxel_index`` int64."""
     n = np.asarray(n, dtype=np.int64).ravel()
@@ -73,31 +142,47 @@ def binomial_half(n: np.ndarray, voxel_index: np.ndarray, iteration: int, seed: 
     out = np.zeros(n.shape, dtype=np.int64)
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     k0, k1 = seed & 0xFFFFFFFF, seed >> 32
-    max_chunks = int((n.max() + 127) // 128) if n.size else 0
-    for chunk in range(max_chunks):
-        remaining = n - 128 * chunk
-        sel = np.nonzero(remaining > 0)[0]
-        if sel.size == 0:
-            break
+    act = np.nonzero(n > 0)[0]
+    if act.size == 0:
+        return out
+
+    def block(sel, number):
         vv = v[sel]
-        w = philox4x32_10(
-            vv & _MASK32,
-            vv >> np.uint64(32),
-            np.full(sel.shape, iteration, dtype=np.uint64),
-            np.full(sel.shape, chunk, dtype=np.uint64),
-            k0,
-            k1,
-            rounds=SPLIT_ROUNDS,
-        )
-        rem = remaining[sel]
-        acc = np.zeros(sel.shape, dtype=np.int64)
-        for i in range(4):
-            nbits = np.clip(rem - 32 * i, 0, 32)
-            mask = np.where(
-                nbits >= 32,
-                np.uint64(0xFFFFFFFF),
-                (np.uint64(1) << nbits.astype(np.uint64)) - np.uint64(1),
-            ).astype(np.uint32)
-            acc += _popcount32(w[i] & mask)
-        out[sel] += acc
+        return philox4x32_10(vv & _MASK32, vv >> np.uint64(32), np.full(sel.shape, iteration, dtype=np.uint64),
+                             np.full(sel.shape, number, dtype=np.uint64), k0, k1, rounds=SPLIT_ROUNDS)
+
+    def masked_popcount(word, nbits):
+        nbits = np.clip(nbits, 0, 32)
+        mask = np.where(nbits >= 32, np.uint64(0xFFFFFFFF),
+                        (np.uint64(1) << nbits.astype(np.uint64)) - np.uint64(1)).astype(np.uint32)
+        return _popcount32(word & mask)
+
+    w = block(act, 0)
+    r = n[act] & 63
+    acc = masked_popcount(w[0], r) + masked_popcount(w[1], r - 32)
+    q = n[act] >> 6
+    hi, lo = w[2].copy(), w[3].copy()
+    pend_hi, pend_lo = np.zeros_like(hi), np.zeros_like(lo)
+    j = 0
+    live = np.nonzero(q > 0)[0]           # positions inside `act`
+    while live.size:
+        qc = np.minimum(q[live], Q_MAX)
+        one = qc == 1
+        add = np.zeros(live.shape, dtype=np.int64)
+        add[one] = _popcount32(hi[live][one]) + _popcount32(lo[live][one])
+        if (~one).any():
+            add[~one] = _table_draw(qc[~one], hi[live][~one], lo[live][~one])
+        acc[live] += add
+        q[live] -= qc
+        live = live[q[live] > 0]
+        if not live.size:
+            break
+        j += 1                              # uniform j: block (j + 1) // 2, words (x, y) for odd j, (z, w) for even j
+        if j & 1:
+            w = block(act[live], (j + 1) >> 1)
+            hi[live], lo[live] = w[0], w[1]
+            pend_hi[live], pend_lo[live] = w[2], w[3]
+        else:
+            hi[live], lo[live] = pend_hi[live], pend_lo[live]
+    out[act] = acc
     return out

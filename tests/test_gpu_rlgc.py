@@ -27,18 +27,50 @@ def _rel_err(a, b):
 
 
 def test_philox_split_is_bit_identical_to_oracle():
+    """Every branch of the bounded-work sampler (csrc/m3d_binom.h): pop-count only (n < 64), q = 1, table rows from
+    the smallest to the largest, row edges, and - float images only - the chunked draw above 65535 counts."""
     kernels = pkg("kernels")
     rng = np.random.default_rng(0)
     img = rng.integers(0, 3000, size=(5, 33, 47)).astype(np.uint16)
-    img[0, 0, :5] = (0, 1, 128, 129, 65535)
+    img[0, 0, :12] = (0, 1, 63, 64, 65, 127, 128, 129, 191, 192, 65472, 65535)
+    img[1] = rng.integers(0, 65536, size=img[1].shape)          # every table row
+    img[2, :8] = rng.integers(60000, 65536, size=img[2, :8].shape)   # a saturated camera
     for it, seed in ((0, 42), (9, 12345678901234)):
         got = kernels.rlgc_debug_split(torch.from_numpy(img).to(DEV), seed, it).cpu().numpy()
         ref = philox.binomial_half(img.astype(np.int64), np.arange(img.size), it, seed)
         assert np.array_equal(got.ravel(), ref.astype(np.float32))
     imgf = (img.astype(np.float32) + 0.75)
+    imgf[3] = rng.integers(65536, 1 << 20, size=imgf[3].shape)  # chunks of 65472 + remainder
+    imgf[4, 0, :4] = (65472.0 * 2, 65472.0 * 2 + 1, 1048576.0, 3e6)   # the last is clamped to 2^20 for the draw
     got = kernels.rlgc_debug_split(torch.from_numpy(imgf).to(DEV), 42, 3).cpu().numpy()
-    ref = philox.binomial_half(imgf.astype(np.int64), np.arange(img.size), 3, 42)
+    ref = philox.binomial_half(np.minimum(imgf, 1048576.0).astype(np.int64), np.arange(img.size), 3, 42)
     assert np.array_equal(got.ravel(), ref.astype(np.float32))
+
+
+def test_table_draws_on_and_around_every_threshold_land_on_the_exact_count():
+    """The device search starts from a float quantile guess (v_log_f32 / v_sqrt_f32 / v_rcp_f32: not the host's
+    arithmetic) and is decided by the integer thresholds: uniforms placed on, one below and one above every
+    threshold of eight rows must give the oracle's count."""
+    from test_binomial_split import threshold_probes
+
+    kernels = pkg("kernels")
+    q, hi, lo, want = threshold_probes(np.random.default_rng(3), (2, 3, 7, 40, 200, 511, 937, 1023), n_random=20000)
+    to = lambda a: torch.from_numpy(a.view(np.int32)).to(DEV).view(torch.uint32)  # noqa: E731
+    got = kernels.binom_debug_table_draw(to(q), to(hi), to(lo)).view(torch.int32).cpu().numpy()
+    assert np.array_equal(got.astype(np.int64), want)
+
+
+def test_split_of_a_bright_volume_has_binomial_moments():
+    """Size-independent property on 2^23 voxels of 60000 counts: mean n / 2 and variance n / 4 of the device draws
+    (the oracle-identical stream, checked on the device so that no table entry is out of place in HBM)."""
+    kernels = pkg("kernels")
+    n = 60000
+    img = torch.full((32, 512, 512), n, dtype=torch.uint16, device=DEV)
+    s = kernels.rlgc_debug_split(img, 7, 1).double()
+    count = s.numel()
+    assert abs(float(s.mean()) - n / 2) < 5 * (n / 4 / count) ** 0.5
+    assert abs(float(s.var()) / (n / 4) - 1.0) < 5 * (2.0 / count) ** 0.5
+    assert float(s.min()) > n / 2 - 7 * (n / 4) ** 0.5 and float(s.max()) < n / 2 + 7 * (n / 4) ** 0.5
 
 
 @pytest.mark.parametrize("name", ["rlgc_a", "rlgc_b"])

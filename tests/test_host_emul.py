@@ -28,8 +28,8 @@ def emul(tmp_path_factory):
 
 def test_philox_binomial_matches_numpy_oracle(emul):
     rng = np.random.default_rng(5)
-    n = np.concatenate([np.arange(0, 300), rng.integers(0, 70000, size=2000),
-                        [65535, 128, 127, 129, 256, 255]]).astype(np.uint32)
+    n = np.concatenate([np.arange(0, 300), rng.integers(0, 70000, size=2000), rng.integers(0, 1 << 20, size=500),
+                        [65535, 128, 127, 129, 256, 255, 63, 64, 65471, 65472, 65473, 130944, 130945, 1 << 20]]).astype(np.uint32)
     vox = rng.integers(0, 2**40, size=n.size).astype(np.uint64)
     out = np.zeros(n.size, dtype=np.uint32)
     for it, seed in ((0, 42), (7, 43), (123, 2**40 + 17)):
