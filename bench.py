@@ -342,11 +342,28 @@ def _free_port() -> int:
         return int(s.getsockname()[1])
 
 
+def visible_gpu_count() -> int:
+    """GPUs this process may use, found WITHOUT a HIP call (the launching parent must stay clear of the runtime): the
+    visibility lists if set, else the compute nodes of the KFD topology (nodes with SIMDs are GPUs)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    count = 0
+    for props in Path("/sys/class/kfd/kfd/topology/nodes").glob("*/properties"):
+        try:
+            fields = dict(line.split()[:2] for line in props.read_text().splitlines() if len(line.split()) >= 2)
+            count += int(fields.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            continue
+    return count
+
+
 def launch_ranks(n: int, argv: list[str]) -> int:
     """``bench.py --gpus N`` started plainly: start N ranks with torch.distributed.run as a CHILD process and
-    pass its output and exit code on.  The parent has made no GPU call (``device_count`` does not initialise
-    HIP on this image) and never execs."""
-    have = torch.cuda.device_count()
+    pass its output and exit code on.  The parent has made no GPU call (GPUs are counted from the environment /
+    sysfs) and never execs."""
+    have = visible_gpu_count()
     if have < n:
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
     env = dict(os.environ)
@@ -477,7 +494,9 @@ def main() -> int:
         current.update(readouts=readouts, predictors=predictors, truth=truth, fiducials=fiducials, shifts=shifts)
         torch.cuda.synchronize(device)
 
-    def deconvolve(image, profile: bool):
+    def deconvolve(image, profile):
+        # profile: True = HIP events around every FFT pass (the warm-up tile: per-pass breakdown), "loop" = only the
+        # two events around each solver call's iteration loop (the timed tiles: roofline.avg_ms)
         _o, info = rl.rlgc_device(image, psf, rng_seed=42, out=decon, profile=profile)
         stats["iters"] += info.iterations
         stats["conv_ms"] += info.conv_ms_total
@@ -593,7 +612,7 @@ def main() -> int:
 
     def record(steps_done: int, warm_done: int, elapsed: float, total_iters: float, tiles_done: int) -> dict:
         value = tiles_done * n_tile / elapsed / 1e6
-        conv_ms = stats["conv_ms"] / max(stats["conv_calls"], 1)
+        conv_ms = passes["conv_ms"] / max(passes["conv_calls"], 1)
         conv_achieved = RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full / (conv_ms * 1e-3) / 1e9 if conv_ms else 0.0
         # one RLGC iteration = the launch unit of the dominant work: SURVEY.md section 8(d) prices it at
         # 148 B per padded voxel (4 convolutions x 20 B + 17 elementwise array passes x 4 B)
@@ -651,11 +670,11 @@ def main() -> int:
                 "bound": "hbm", "achieved": round(conv_achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(conv_achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(padded, "fft_conv_hbm_bytes_per_launch"), "avg_ms": round(conv_ms, 3),
-                "launches": stats["conv_calls"],
+                "launches": passes["conv_calls"], "sampled_on": "the untimed first tile",
                 "algorithmic_bytes_per_launch": RLGC_ALGORITHMIC_BYTES_PER_CONV_VOXEL * np_full,
             },
         }
-        if stats["fused"] and stats["conv_calls"]:
+        if stats["fused"] and passes["conv_calls"]:
             # the five kernels of one convolution, with the bytes each one actually has to move
             names = ("k_x_forward", "k_y_pass<fwd>", "k_z_conv", "k_y_pass<inv>", "k_x_inverse")
             # B per padded voxel each pass has to move (half spectrum = 4 B / voxel), averaged over the four
@@ -671,10 +690,10 @@ def main() -> int:
             moved = (3.0 * x_small / 4, (3.0 * y_small + 8.0) / 4, 5.0 * fz + 7.0, (y_small + 8.0) / 2,
                      (x_small + x_dual + x_update) / 4)
             out["roofline_kernels"] = [
-                {"kernel": nme, "avg_ms": round(ms / stats["conv_calls"], 3),
-                 "hbm_gbs": round(bpv * np_full / (ms / stats["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
+                {"kernel": nme, "avg_ms": round(ms / passes["conv_calls"], 3),
+                 "hbm_gbs": round(bpv * np_full / (ms / passes["conv_calls"] * 1e-3) / 1e9, 1) if ms else None,
                  "bytes_per_voxel": round(bpv, 2)}
-                for nme, ms, bpv in zip(names, stats["kernel_ms"], moved)]
+                for nme, ms, bpv in zip(names, passes["kernel_ms"], moved)]
         if strong and stats["reg_calls"]:
             out["registration"] = {
                 "what": "register_pair_to_fixed per moving round (host wall time around the call, first-seen "
@@ -721,12 +740,14 @@ def main() -> int:
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     if strong:
-        register_rounds(False)
-    deconvolve_bits(False)
+        register_rounds(True)
+    deconvolve_bits(True)
     fix_normalization()
     decode()
     torch.cuda.synchronize(device)
     first_tile_s = time.perf_counter() - t0
+    # per-pass breakdown (events around every FFT pass, ~6 500 per tile): sampled here, outside the timed region
+    passes = {"conv_ms": stats["conv_ms"], "conv_calls": stats["conv_calls"], "kernel_ms": list(stats["kernel_ms"])}
     if strong and stats["reg_calls"]:   # the process's first calls: every transform shape is new to rocFFT here
         extras["registration_first_tile"] = {"calls": stats["reg_calls"],
                                              "avg_s": round(stats["reg_s"] / stats["reg_calls"], 4),
@@ -757,7 +778,7 @@ def main() -> int:
         for _ in range(min(max(args.warmup - 1, 0), 1)):
             if seconds_left() < 4.5 * first_tile_s:
                 break
-            step(False)
+            step("loop")
             warm_done += 1
         n_steps = agree_min(steps_that_fit(args.steps, first_tile_s, seconds_left()), world, device)
     reset_stats()
@@ -776,7 +797,7 @@ def main() -> int:
         sync()
         t0 = time.perf_counter()
         if mine:
-            step(True)
+            step("loop")
             tiles_done_rank += 1
         sync()
         elapsed_sum += time.perf_counter() - t0

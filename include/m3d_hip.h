@@ -63,7 +63,8 @@ typedef struct m3d_rlgc_params {
     uint64_t seed;          /* rlgc.py:564: split seed (42; +tile_idx when tiled, :983)     */
     int32_t normalize_psf;  /* rlgc.py:310-312                                              */
     int32_t max_iterations; /* 0 = unbounded like the reference; >0 is a test/bench bound   */
-    int32_t profile;        /* != 0: HIP-event timing of every FFT convolution (bench.py)   */
+    int32_t profile;        /* bit 0: HIP events around every FFT pass; bit 1: only the two events around the
+                               iteration loop (loop_ms); 0: none (bench.py)                                  */
     int32_t reserved;
 } m3d_rlgc_params;
 

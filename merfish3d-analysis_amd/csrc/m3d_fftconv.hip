@@ -478,43 +478,6 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(float2 *__restrict__ spe
     }
 }
 
-// In-kernel phase stamps (diagnostic builds only: -DM3D_STAMPS; scripts/gpu_stamps.py reads them back).
-#ifdef M3D_STAMPS
-__device__ unsigned long long m3d_stamp_buf[512 * 16];
-#define M3D_STAMP_DECL unsigned long long ts_[16]; for (int i_ = 0; i_ < 16; ++i_) ts_[i_] = 0; \
-    const bool stamp_on_ = threadIdx.x == M3D_STAMP_TID && blockIdx.x >= 8192 && blockIdx.x < 8192 + 512;
-#define M3D_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (stamp_on_) ts_[i] = __builtin_amdgcn_s_memtime(); \
-    __builtin_amdgcn_sched_barrier(0); } while (0)
-#define M3D_STAMP_FLUSH do { if (stamp_on_) { ts_[15] = __builtin_amdgcn_s_memrealtime(); \
-    for (int i_ = 0; i_ < 16; ++i_) m3d_stamp_buf[(blockIdx.x - 8192) * 16 + i_] = ts_[i_]; } } while (0)
-#ifndef M3D_STAMP_TID
-#define M3D_STAMP_TID 0
-#endif
-#else
-#define M3D_STAMP_DECL
-#define M3D_STAMP(i) do { } while (0)
-#define M3D_STAMP_FLUSH do { } while (0)
-#endif
-// -DM3D_STAMPS=1 stamps the forward X pass, =2 the dual inverse
-#if defined(M3D_STAMPS) && M3D_STAMPS == 1
-#define M3D_FSTAMP_DECL M3D_STAMP_DECL
-#define M3D_FSTAMP(i) M3D_STAMP(i)
-#define M3D_FSTAMP_FLUSH M3D_STAMP_FLUSH
-#else
-#define M3D_FSTAMP_DECL
-#define M3D_FSTAMP(i) do { } while (0)
-#define M3D_FSTAMP_FLUSH do { } while (0)
-#endif
-#if defined(M3D_STAMPS) && M3D_STAMPS == 2
-#define M3D_DSTAMP_DECL M3D_STAMP_DECL
-#define M3D_DSTAMP(i) M3D_STAMP(i)
-#define M3D_DSTAMP_FLUSH M3D_STAMP_FLUSH
-#else
-#define M3D_DSTAMP_DECL
-#define M3D_DSTAMP(i) do { } while (0)
-#define M3D_DSTAMP_FLUSH do { } while (0)
-#endif
-
 // ================================================================ X passes with register edge stages
 // PMC passes over the kernels above (profiles/r02_pmc_sq_rlgc_before.json): waves parked on s_waitcnt / barriers half
 // of their lifetime, 30 % of the LDS cycles lost to bank conflicts, and the gather / split phases - chains of dependent
@@ -623,10 +586,8 @@ __device__ __forceinline__ void forward_pair_load(const float2 *row, int u1, int
     for (int q = 0; q < 9; ++q) c1[q] = row[9 * u1 + q];
 #pragma unroll
     for (int q = 0; q < 9; ++q) c2[q] = row[9 * u2 + q];
-#ifndef M3D_XF_COPYONLY
     dft9<false>(c1);
     dft9<false>(c2);
-#endif
 }
 
 // Hermitian split of the pair: A (first packed real row) and B for the nine frequencies k < Xc of the pair, written
@@ -640,9 +601,6 @@ __device__ __forceinline__ void forward_pair_emit(const float2 (&c1)[9], const f
     int rows_c = 0;
     const int rbase = STAGED ? 0 : row_base(g, min(ya, g.Yp - 1), rows_c);
     auto put = [&](int k, float2 c, float2 m) {
-#ifdef M3D_XF_NOSTORE
-        if (c.x != 1.2345e30f) return;
-#endif
         if constexpr (STAGED) {
             stage[stage_slot(k, r0)] = make_float2(0.5f * (c.x + m.x), 0.5f * (c.y - m.y));
             stage[stage_slot(k, r0 + 1)] = make_float2(0.5f * (c.y + m.y), 0.5f * (m.x - c.x));
@@ -741,8 +699,6 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
-    M3D_FSTAMP_DECL
-    M3D_FSTAMP(0);
     // the pair item of the last stage: its two block positions are requested now, used three barriers later
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     const bool pair_live = tid < nb * I;
@@ -768,13 +724,8 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
                 int n = tid + S * q;
                 if (g.mirror) n = sym_src(n, g.mir.x0, g.mir.nx);
                 else n = min(max(n, g.in.x0), x_hi - 1);
-#ifdef M3D_XF_NOLOAD
-                a[q] = (float)n * 1e-3f;
-                b[q] = (float)(n + ya) * 1e-3f;
-#else
                 a[q] = ra[n];
                 b[q] = rbp[n];
-#endif
             }
             float2 v[9];
 #pragma unroll
@@ -783,23 +734,15 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
                 const bool vx = g.mirror || (n >= g.in.x0 && n < x_hi);
                 v[q] = make_float2(va && vx ? a[q] : 0.0f, vb && vx ? b[q] : 0.0f);
             }
-            M3D_FSTAMP(1 + 2 * bi);   // loads of this row pair have landed
-#ifndef M3D_XF_COPYONLY
             dft9<false>(v);
-#endif
             float2 *row = lds_fr + bi * N + tid;
             row[0] = v[0];
 #pragma unroll
             for (int q = 1; q < 9; ++q) row[S * q] = cmul(v[q], w[q]);
-            M3D_FSTAMP(2 + 2 * bi);   // first stage done
         }
     }
     __syncthreads();
-    M3D_FSTAMP(5);
-#if !defined(M3D_XF_NOMID) && !defined(M3D_XF_COPYONLY)
     middle_forward<RSET, NS>(lds_fr, ax, nb, N, tid, nt, g.GX);
-#endif
-    M3D_FSTAMP(6);
     {
         float2 c1[9], c2[9];
         if (pair_live) forward_pair_load(lds_fr + pbi * N, pu1 / 9, pu2 / 9, c1, c2);
@@ -819,20 +762,24 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
                                      ya + 1 >= g.in.y0 && ya + 1 < y_hi);
         }
     }
-    M3D_FSTAMP(7);
-#if defined(M3D_STAMPS) && M3D_STAMPS == 1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    M3D_FSTAMP(8);
-    M3D_FSTAMP_FLUSH;
 }
 
 // Fused tails run on the registers of the last inverse stage: thread t holds x[t + S q] of both packed rows.
 // CHAIN (kUpdate, compile-time geometry): the updated estimate's rows go straight into the X forward transform of the
 // next iteration's forward-model convolution - symmetric extension along x gathered from the row in LDS, the same
 // stages and stores as k_x_forward_reg - written over the spectrum rows this workgroup read (ep.chain == spec).
+// The spectrum argument: read-only and restrict-qualified, except in the CHAIN build, which writes the next
+// convolution's rows over the rows it has read - there it is a plain pointer the compiler may not assume invariant.
+template <bool CHAIN>
+struct SpecArg {
+    typedef const float2 *__restrict__ type;
+};
+template <>
+struct SpecArg<true> {
+    typedef float2 *type;
+};
 template <int RSET, int EPI, int NS = 0, bool CHAIN = false>
-__global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restrict__ spec, float *__restrict__ dst,
+__global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN>::type spec, float *__restrict__ dst,
                                                       ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
@@ -862,14 +809,19 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
         const float2 *sb = spec + (int64_t)z * g.plane + rbb;
         float2 Av[9], Bv[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            Av[i] = sa[off[i]];
-            Bv[i] = sb[off[i]];
-        }
+        for (int i = 0; i < 9; ++i) Av[i] = Bv[i] = make_float2(0.f, 0.f);
+        if (va || vb) {  // a pair wholly outside the box is zero: no load (in the CHAIN build another workgroup may be
+                         // rewriting the row this one would otherwise read as a stand-in)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            if (!va) Av[i] = make_float2(0.f, 0.f);
-            if (!vb) Bv[i] = make_float2(0.f, 0.f);
+            for (int i = 0; i < 9; ++i) {
+                Av[i] = sa[off[i]];
+                Bv[i] = sb[off[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (!va) Av[i] = make_float2(0.f, 0.f);
+                if (!vb) Bv[i] = make_float2(0.f, 0.f);
+            }
         }
         inverse_pair_merge(lds_ir + pbi * N, S, N, kp, u1 / 9, u2 / 9, Av, Bv);
     }
@@ -972,9 +924,9 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(const float2 *__restri
             if (pair_live) forward_pair_load(lds_ir + pbi * N, u1 / 9, u2 / 9, c1, c2);
             const int64_t zterm = (int64_t)z * g.plane;
             __syncthreads();  // every pair has read its blocks: the buffer becomes the line staging
-            // ep.chain == spec (checked by the host): store through a pointer derived from `spec` itself, so that the
-            // restrict qualifier of the read pointer stays honest
-            float2 *chain = const_cast<float2 *>(spec);
+            float2 *chain;  // ep.chain == spec (checked by the host)
+            if constexpr (CHAIN) chain = spec;
+            else chain = nullptr;
             if (pair_live) forward_pair_emit<true>(c1, c2, g, S, kp, chain, zterm, y0 + 2 * pbi, true, true, lds_ir, 2 * pbi);
             __syncthreads();
             unsigned rows_ok = 0;
@@ -1030,11 +982,6 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     const int z = item / groups, y0 = (item % groups) * 2;
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     const bool pair_live = tid < 2 * I;
-#ifdef M3D_XD_EMPTY
-    if (g_.Xp != -12345) return;
-#endif
-    M3D_DSTAMP_DECL
-    M3D_DSTAMP(0);
     int pu1 = 0, pu2 = 0;
     if (pair_live) {
         pu1 = ax.pos[kp] / 9;
@@ -1046,28 +993,13 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         float2 Av[9], Bv[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-#ifdef M3D_XD_NOLOAD
-            Av[i] = make_float2(1.0f + (float)(kp + i) * 1e-3f, 0.25f);
-            Bv[i] = make_float2(0.5f, (float)(kp - i) * 1e-3f);
-#else
             Av[i] = spec1[rbase + off[i]];
             Bv[i] = spec2[rbase + off[i]];
-#endif
         }
-#if defined(M3D_STAMPS) && M3D_STAMPS == 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        M3D_DSTAMP(1);
         inverse_pair_merge(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
     }
-    M3D_DSTAMP(2);
     __syncthreads();
-    M3D_DSTAMP(3);
-#ifndef M3D_XD_NOMID
     middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
-#else
-    __syncthreads();
-#endif
     // 1 / update_norm of both rows.  Requested here, not in front of the middle stages: 18 registers held across
     // them cost more (spills, 3.23 -> 3.04 ms) than the exposed latency of these coalesced loads
     const bool row1 = y0 + 1 < g.Yp;
@@ -1076,16 +1008,10 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     if (tid < S) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
-#ifdef M3D_XD_NOUN
-            un0[q] = 1.0f + (float)q;
-            un1[q] = 2.0f + (float)q;
-#else
             un0[q] = ep.b[r0 + tid + S * q];
             un1[q] = ep.b[r1 + tid + S * q];
-#endif
         }
     }
-    M3D_DSTAMP(4);
     float mn = INFINITY, mx = -INFINITY;
     if (tid < S) {
         float2 w[9];
@@ -1114,11 +1040,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
                     const float hs = h1 + h2;
                     mn = fminf(mn, hs);
                     mx = fmaxf(mx, hs);
-#ifdef M3D_XD_NOUN
-                    if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx && hs == 1.2345e30f) ep.o2[rr + n] = hs;
-#else
                     if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[rr + n] = hs;
-#endif
                     if constexpr (!CHAIN) ep.o1[rr + n] = prod;
                 }
                 if (r == 0) pk[q] = make_float2(prod, 0.0f);
@@ -1137,7 +1059,6 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
         }
     }
-    M3D_DSTAMP(5);
     // per-wave extrema ride the barrier the chained forward needs anyway
     mn = m3d::wave_min(mn);
     mx = m3d::wave_max(mx);
@@ -1150,34 +1071,19 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         unsigned int *red = red_slot(ep.red);
         mn = fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3]));
         mx = fmaxf(fmaxf(smf[4], smf[5]), fmaxf(smf[6], smf[7]));
-#ifdef M3D_XD_NOATOM
-        if (mn == 1.2345e30f)
-#endif
         {
             atomicMin(&red[0], m3d::float_key(mn));
             atomicMax(&red[1], m3d::float_key(mx));
         }
     }
-    M3D_DSTAMP(6);
     if constexpr (CHAIN) {
-#ifndef M3D_XD_NOMID
         middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
-#else
-        __syncthreads();
-#endif
-        M3D_DSTAMP(7);
         if (tid < I) {
             float2 c1[9], c2[9];
             forward_pair_load(lds_dr, pu1, pu2, c1, c2);
             forward_pair_emit<false>(c1, c2, g, S, kp, spec1, (int64_t)z * g.plane, y0, true, row1);
         }
     }
-    M3D_DSTAMP(8);
-#if defined(M3D_STAMPS) && M3D_STAMPS == 2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    M3D_DSTAMP(9);
-    M3D_DSTAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------- Y pass (in place)
@@ -1932,20 +1838,19 @@ static int row_groups(const FftConvPlan *p, const m3d::ConvBox &b)
 }
 
 // One Z pass (mode -1: forward only, OTF construction) with the kernel family the plan uses throughout.
-static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, const ConvGeo &g, int mode, float scale,
-                     hipStream_t st, float2 *spec_b = nullptr)
+static int launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, const ConvGeo &g, int mode, float scale,
+                    hipStream_t st, float2 *spec_b = nullptr)
 {
     const unsigned nblk = (unsigned)((p->plane + p->P - 1) / p->P);
     // a real |OTF|^2 volume (mode 3) exists for the register Z pass with zero-extended input and cropped output (the
     // consensus convolution); callers check fftconv_real_otf_supported and pass it for that geometry only
     if (mode == 3 && (!p->zreg || g.zmirror || (g.out.z0 == 0 && g.out.nz == p->Zp))) {
         set_err("fftconv", "mode 3 outside the geometry it is built for");
-        return;
+        return M3D_ERR_INVALID_ARG;
     }
     if (!p->zreg && spec_b) {  // the LDS variant has no paired form
-        launch_z(p, spec, otf, g, mode, scale, st);
-        launch_z(p, spec_b, otf, g, mode, scale, st);
-        return;
+        if (int rc = launch_z(p, spec, otf, g, mode, scale, st)) return rc;
+        return launch_z(p, spec_b, otf, g, mode, scale, st);
     }
     if (p->zreg) {
         static const int zp_env = [] { const char *e = getenv("M3D_FFT_ZREG_P"); return e ? atoi(e) : 0; }();  // 256-byte segments: 4 % faster
@@ -1992,6 +1897,7 @@ static void launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, cons
         hipLaunchKernelGGL(k_z_conv<1>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
     else
         hipLaunchKernelGGL(k_z_conv<0>, dim3(nblk), dim3(p->zthreads), p->lds_z, st, spec, otf, g, p->az, mode, scale);
+    return M3D_OK;
 }
 
 // Y pass: the static-geometry build when the plan is the headline one (2187 = 9 * 9 * 9 * 3, TW 4, 128-row chunks,
@@ -2075,7 +1981,7 @@ int fftconv_make_otf(const FftConvPlan *p, const float *psf_padded, float2 *otf,
     int rc = launch_forward_xy(p, psf_padded, otf, st);
     if (rc) return rc;
     const ConvGeo g = geo_of(p);
-    launch_z(p, otf, (const float2 *)nullptr, g, -1, 1.0f, st);
+    if ((rc = launch_z(p, otf, (const float2 *)nullptr, g, -1, 1.0f, st))) return rc;
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }
@@ -2104,7 +2010,7 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
     g.zmirror = (mirrored && p->zmirror) ? 1 : 0;
     if (g.zmirror && g.in.z0 <= g.in.nz && p->Zp - (g.in.z0 + g.in.nz) <= g.in.nz) g.zmirror = 2;  // single reflection
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
-    launch_z(p, spec, otf, g, mode, scale, st);
+    if ((rc = launch_z(p, spec, otf, g, mode, scale, st))) return rc;
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
     launch_y_pass<true>(p, spec, g, g.out.nz, st);
     if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
@@ -2137,14 +2043,21 @@ int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *s
 {
     hipStream_t st = (hipStream_t)stream;
     if (!src1 || !src2 || !spec1 || !spec2 || spec1 == spec2 || !box_ok(p, in_box)) return M3D_ERR_INVALID_ARG;
-    int rc = launch_forward_xy(p, src1, spec1, st, log, in_box, nullptr, nullptr);
-    if (!rc) rc = launch_forward_xy(p, src2, spec2, st, log, in_box, nullptr, nullptr);
-    if (rc) return rc;
-    if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
+    // one span of the event log: both X passes, then both Y passes (two launch_forward_xy calls would open a second
+    // span in the middle and drop the first spectrum's Y pass from the attribution)
     ConvGeo g = geo_of(p, in_box, nullptr);
     g.zmirror = 0;
+    const int groups = row_groups(p, g.in);
+    if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
+    launch_x_forward(p, src1, spec1, g, groups, st);
+    launch_x_forward(p, src2, spec2, g, groups, st);
+    if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
+    launch_y_pass<false>(p, spec1, g, g.in.nz, st);
+    launch_y_pass<false>(p, spec2, g, g.in.nz, st);
+    M3D_KERNEL_CHECK();
+    if (log && log->mark(EventLog::kYF)) return M3D_ERR_HIP;
     const float scale = 1.0f / ((float)p->Zp * (float)p->Yp * (float)p->Xp);
-    launch_z(p, spec1, otf, g, mode, scale, st, spec2);
+    if (int rc = launch_z(p, spec1, otf, g, mode, scale, st, spec2)) return rc;
     if (log && log->mark(EventLog::kZ)) return M3D_ERR_HIP;
     launch_y_pass<true>(p, spec1, g, g.out.nz, st);
     launch_y_pass<true>(p, spec2, g, g.out.nz, st);
@@ -2253,9 +2166,3 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
 
 }  // namespace m3d
 
-#ifdef M3D_STAMPS
-extern "C" int m3d_debug_stamps(unsigned long long *host, int count)
-{
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(m3d_stamp_buf), sizeof(unsigned long long) * (size_t)count) == hipSuccess ? 0 : -3;
-}
-#endif

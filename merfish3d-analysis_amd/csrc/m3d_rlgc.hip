@@ -873,7 +873,8 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     m3d::EventLog elog;
     elog.events = &p->events;
     elog.stream = st;
-    elog.enabled = params->profile != 0;
+    elog.enabled = (params->profile & 1) != 0;  // bit 0: events around every pass; bit 1: the loop's two events only
+    const bool time_loop = params->profile != 0;
     auto stamp = [&](int kind) -> int {
         if (elog.mark(kind)) {
             set_err("hipEventRecord", "profiling event");
@@ -893,6 +894,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     // ... and the elementwise kernels that follow the second ratio convolution and the consensus
     // convolution run inside those convolutions' X inverse store loops (ConvEpilogue).
     const bool fused_tail = p->fc && prune;
+    // the fused tails' reduction records (m3d_fftconv.h) live in the partial-sum arrays of the unfused kernels
+    static_assert(sizeof(MinMaxPartial) * kRowGrid >= sizeof(unsigned int) * m3d::kRedSlots * m3d::kRedStride,
+                  "consensus reduction records do not fit the min/max partials they alias");
+    static_assert(sizeof(UpdPartial) * kRowGrid >= sizeof(unsigned int) * m3d::kRedSlots * m3d::kRedStride,
+                  "update reduction records do not fit the update partials they alias");
     unsigned int *cons_red = (unsigned int *)mm_part, *upd_red = (unsigned int *)up_part;
     auto conv = [&](float *src, int mode, float *dst, int support = kFull,
                     const m3d::ConvEpilogue *epi = nullptr, bool x_forward_done = false) -> int {
@@ -1048,7 +1054,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     int num_iters = 0, stop = 0;
     float *result = nullptr;
 
-    if (elog.enabled) {
+    if (time_loop) {
         for (hipEvent_t &e : p->loop_ev)
             if (!e) M3D_HIP_CHECK(hipEventCreate(&e));
         M3D_HIP_CHECK(hipEventRecord(p->loop_ev[0], st));
@@ -1110,7 +1116,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         }
     }
     if (num_iters == 0 && stop == 1) result = recon_cur;  // cannot happen (prev = inf); safety
-    if (elog.enabled) M3D_HIP_CHECK(hipEventRecord(p->loop_ev[1], st));
+    if (time_loop) M3D_HIP_CHECK(hipEventRecord(p->loop_ev[1], st));
     hipLaunchKernelGGL(k_crop, dim3(g_core), rb, 0, st, result, out, g);
     M3D_KERNEL_CHECK();
     M3D_HIP_CHECK(hipStreamSynchronize(st));
@@ -1132,7 +1138,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         res->conv_ms_total = total;
         res->fused_engine = p->fc ? 1 : 0;
         float loop_ms = 0.0f;
-        if (elog.enabled && hipEventElapsedTime(&loop_ms, p->loop_ev[0], p->loop_ev[1]) != hipSuccess) loop_ms = 0.0f;
+        if (time_loop && hipEventElapsedTime(&loop_ms, p->loop_ev[0], p->loop_ev[1]) != hipSuccess) loop_ms = 0.0f;
         res->loop_ms = loop_ms;
     }
     return M3D_OK;

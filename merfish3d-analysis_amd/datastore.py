@@ -33,7 +33,15 @@ class InMemoryDataStore:
 
     def __init__(self, *, num_tiles: int, num_rounds: int, num_bits: int, codebook: pd.DataFrame,
                  voxel_size_zyx_um=(0.315, 0.098, 0.098), microscope_type: str = "3D",
-                 datastore_path: str | Path = "/tmp/m3d_inmemory_datastore"):
+                 datastore_path: str | Path = "/tmp/m3d_inmemory_datastore", **experiment):
+        # experiment constants of qi2labDataStore (experiment_order, channels_in_data, camera_model, tile_overlap,
+        # binning, na, ri, e_per_ADU): kept as attributes, the disk store writes them to calibrations/attributes.json
+        unknown = set(experiment) - {"experiment_order", "channels_in_data", "camera_model", "tile_overlap", "binning",
+                                     "na", "ri", "e_per_ADU"}
+        if unknown:
+            raise TypeError(f"unknown creation arguments: {sorted(unknown)}")
+        for key, value in experiment.items():
+            setattr(self, key, value)
         self.tile_ids = [f"tile{i:04d}" for i in range(num_tiles)]
         self.round_ids = [f"round{i + 1:03d}" for i in range(num_rounds)]
         self.bit_ids = [f"bit{i + 1:03d}" for i in range(num_bits)]
@@ -62,6 +70,14 @@ class InMemoryDataStore:
         self._decoded = {}
         self._filtered = {}
         self._predictor_spots = {}
+        order = experiment.get("experiment_order")
+        if order is not None:   # initialize_tile (qi2labDataStore.py:2840-2960): bit <-> round links from the order
+            order = np.asarray(order, dtype=np.int64)
+            for tile in self.tile_ids:
+                for b, bit_id in enumerate(self.bit_ids):
+                    rows = np.nonzero((order[:, 1:] == b + 1).any(axis=1))[0]
+                    if rows.size:
+                        self._round_linker[(tile, bit_id)] = int(order[rows[0], 0])
 
     # ---- id helpers (qi2labDataStore.py:2501-2515) ------------------------------------
     @property
@@ -107,6 +123,31 @@ class InMemoryDataStore:
         k = self._key(tile, round, bit)
         self._corrected[k] = image
         self._wavelengths[k] = tuple(float(v) for v in wavelengths_um)
+
+    def save_local_corrected_image(self, image, tile, gain_correction: bool = True, hotpixel_correction: bool = True,
+                                   shading_correction: bool = False, psf_idx: int = 0, round=None, bit=None,
+                                   return_future=False):
+        """qi2labDataStore.save_local_corrected_image (:3639-3770): the image plus its correction flags and PSF index."""
+        k = self._key(tile, round, bit)
+        if k is None:
+            return None
+        self._corrected[k] = image
+        self._image_attributes(k).update({"gain_correction": bool(gain_correction),
+                                          "hotpixel_correction": bool(hotpixel_correction),
+                                          "shading_correction": bool(shading_correction), "psf_idx": int(psf_idx)})
+
+    def _image_attributes(self, key) -> dict:
+        if not hasattr(self, "_image_attrs"):
+            self._image_attrs = {}
+        return self._image_attrs.setdefault(key, {})
+
+    def save_local_wavelengths_um(self, wavelengths_um, tile, round=None, bit=None):
+        k = self._key(tile, round, bit)
+        if k is not None:
+            self._wavelengths[k] = tuple(float(v) for v in wavelengths_um)
+
+    def save_local_stage_position_zyx_um(self, stage_zyx_um, affine_zyx_px, tile, round):
+        self.set_stage_position_zyx_um(tile, stage_zyx_um, affine_zyx_px, round=round)
 
     def load_local_corrected_image(self, tile, round=None, bit=None, return_future=True):
         k = self._key(tile, round, bit)
@@ -194,7 +235,8 @@ class InMemoryDataStore:
 
     def set_stage_position_zyx_um(self, tile, origin, camera_to_stage=None, round=0):
         c2s = np.eye(4, dtype=np.float32) if camera_to_stage is None else np.asarray(camera_to_stage)
-        self._stage[(self._tile(tile), int(round))] = (np.asarray(origin, dtype=np.float32), c2s)
+        r = round if isinstance(round, (int, np.integer)) else self.round_ids.index(round)
+        self._stage[(self._tile(tile), int(r))] = (np.asarray(origin, dtype=np.float32), c2s)
 
     def load_local_stage_position_zyx_um(self, tile, round=0):
         r = round if isinstance(round, (int, np.integer)) else self.round_ids.index(round)

@@ -73,6 +73,7 @@ class Qi2labDiskStore(ZarrImageDataStore):
             kwargs["voxel_size_zyx_um"] = create.pop("voxel_size_zyx_um", (0.315, 0.098, 0.098))
             kwargs["microscope_type"] = create.pop("microscope_type", "3D")
         super().__init__(root, device=device, num_threads=num_threads, **kwargs)
+        self._attr_cache = {}
         self._calibrations_zarr_path = root / "calibrations"
         self._decoded_root_path = root / "decoded"
         self._segmentation_root_path = root / "segmentation"
@@ -312,6 +313,19 @@ class Qi2labDiskStore(ZarrImageDataStore):
         k = self._key(tile, round, bit)
         self._corrected[k] = image
         self.save_local_wavelengths_um(wavelengths_um, tile, round=round, bit=bit)
+
+    def save_local_corrected_image(self, image, tile, gain_correction: bool = True, hotpixel_correction: bool = True,
+                                   shading_correction: bool = False, psf_idx: int = 0, round=None, bit=None,
+                                   return_future=False):
+        """:3639-3770 - the image store plus the correction flags and PSF index in the entity's sidecar."""
+        k = self._key(tile, round, bit)
+        root = self._entity(tile, round, bit)
+        if k is None or root is None:
+            return None
+        self._corrected[k] = image
+        self._save_entity_attributes(root, {"gain_correction": bool(gain_correction),
+                                            "hotpixel_correction": bool(hotpixel_correction),
+                                            "shading_correction": bool(shading_correction), "psf_idx": int(psf_idx)})
 
     def load_local_round_transform_zyx_um(self, tile, round):
         root = self._entity(tile, round=round)

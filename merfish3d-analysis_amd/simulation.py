@@ -16,11 +16,14 @@ Host-side counterparts of the reference's simulation CLI, which is what its only
 * ``make_simulation``     - the build's own generator of a dataset in that on-disk format (the published simulation
   is a download; there is no network here).
 
-Differences from the reference, all forced by what the image holds: TIFF files are read and written by the small
-baseline reader / writer below (uncompressed strips, tifffile's ``{"shape": ...}`` description; tifffile itself is
-absent), and the PSFs come from ``gaussian_widefield_psf`` unless a ``psf_factory`` is passed (the reference calls
-``psfmodels.make_psf(model="vectorial")``, absent as well).  Both are stated in DESIGN.md; parity of this module is
-semantic (read from the source), not pinned by a reference run.
+Pinning.  ``convert_simulation`` and ``convert_data`` are checked against a run of the reference's own functions
+(tests/golden/make_golden_simulation.py -> tests/test_simulation_reference_run.py): the acquisition folder file by file,
+every stored image, every JSON sidecar of the datastore tree.  The one stand-in under that run that is code of this
+module - the TIFF codec below, used because the main interpreter has no tifffile - is itself pinned in both directions
+against the real tifffile 2021.7.2 of the image's conda Python (tests/golden/make_golden_tiff.py): it reads what
+tifffile writes (the RGB(A)-planar pages tifffile picks for a leading axis of 3 or 4 included) and tifffile reads what it
+writes.  Still a stand-in: the PSFs come from ``gaussian_widefield_psf`` unless a ``psf_factory`` is passed (the
+reference calls ``psfmodels.make_psf(model="vectorial")``; psfmodels is absent from every interpreter of the image).
 """
 
 from __future__ import annotations
@@ -161,14 +164,27 @@ def read_tiff(path) -> np.ndarray:
         if tags.get(259, 1) != 1:
             raise ValueError(f"{path}: compressed TIFF pages are not supported")
         nx, ny = int(tags[256]), int(tags[257])
-        dtype = _TIFF_DTYPES.get((int(tags.get(339, 1)), int(tags.get(258, 1))))
-        if dtype is None or int(tags.get(277, 1)) != 1:
+        first = lambda v, d: d if v is None else (v[0] if isinstance(v, tuple) else v)  # noqa: E731
+        samples = int(tags.get(277, 1))
+        bits, fmt = tags.get(258, 1), tags.get(339, 1)
+        if any(isinstance(v, tuple) and len(set(v)) != 1 for v in (bits, fmt)):
+            raise ValueError(f"{path}: samples of different types in one page")
+        dtype = _TIFF_DTYPES.get((int(first(fmt, 1)), int(first(bits, 1))))
+        if dtype is None:
             raise ValueError(f"{path}: unsupported sample layout")
-        offs, cnts = tags[273], tags.get(279, ny * nx * np.dtype(dtype).itemsize)
+        offs, cnts = tags[273], tags.get(279, samples * ny * nx * np.dtype(dtype).itemsize)
         offs = offs if isinstance(offs, tuple) else (offs,)
         cnts = cnts if isinstance(cnts, tuple) else (cnts,)
         raw = b"".join(buf[o:o + c] for o, c in zip(offs, cnts))
-        pages.append(np.frombuffer(raw, dtype=np.dtype(dtype).newbyteorder(order), count=ny * nx).reshape(ny, nx))
+        page = np.frombuffer(raw, dtype=np.dtype(dtype).newbyteorder(order), count=samples * ny * nx)
+        # tifffile stores a leading axis of length 3 or 4 as the samples of an RGB(A) page: separate planes
+        # (PlanarConfiguration 2, what it chooses for (3, y, x) stacks) or interleaved
+        if samples == 1:
+            pages.append(page.reshape(ny, nx))
+        elif int(tags.get(284, 1)) == 2:
+            pages.append(page.reshape(samples, ny, nx))
+        else:
+            pages.append(page.reshape(ny, nx, samples))
         if shape_hint is None and 270 in tags and tags[270].startswith("{"):
             try:
                 shape_hint = tuple(int(v) for v in json.loads(tags[270])["shape"])
@@ -264,7 +280,8 @@ def convert_data(root_path, datastore_factory: Callable | None = None, *, codebo
                  synthetic_chromatic_edge_shifts_px=(0.0, 0.5, 1.0), synthetic_chromatic_z_shifts_px=(0.0, 0.25, 0.5),
                  synthetic_chromatic_max_z_shifts_px=(0.0, 1.25, 2.5),
                  excitation_wavelengths_um=(0.488, 0.561, 0.635), emission_wavelengths_um=(0.520, 0.580, 0.670),
-                 three_dimensional_z_spacing_threshold_um: float = 0.5, psf_factory: Callable | None = None):
+                 three_dimensional_z_spacing_threshold_um: float = 0.5, psf_factory: Callable | None = None,
+                 channel_names: Sequence[str] | None = None, default_tile_overlap: float = 0.2):
     """Acquisition folder -> datastore (convert_to_datastore.py:185-573) and return the datastore.
 
     ``datastore_factory(num_tiles=, num_rounds=, num_bits=, codebook=, voxel_size_zyx_um=, microscope_type=)`` builds
@@ -295,9 +312,16 @@ def convert_data(root_path, datastore_factory: Callable | None = None, *, codebo
     except KeyError:
         microscope_type = "3D" if voxel[0] < three_dimensional_z_spacing_threshold_um else "2D"
     num_bits = int(np.max(experiment_order[:, 1:]))
+    try:
+        tile_overlap = md["tile_overlap"]
+    except KeyError:
+        tile_overlap = default_tile_overlap
     factory = datastore_factory or InMemoryDataStore
     store = factory(num_tiles=int(num_tiles), num_rounds=int(num_rounds), num_bits=num_bits, codebook=codebook,
-                    voxel_size_zyx_um=tuple(float(v) for v in voxel), microscope_type=str(microscope_type))
+                    voxel_size_zyx_um=tuple(float(v) for v in voxel), microscope_type=str(microscope_type),
+                    experiment_order=experiment_order, channels_in_data=list(channel_names or
+                                                                              ["alexa488", "atto565", "alexa647"]),
+                    camera_model="synthetic", tile_overlap=tile_overlap, binning=1, na=na, ri=ri, e_per_ADU=e_per_adu)
     make_psf = psf_factory or gaussian_widefield_psf
     psfs = []
     for ch in channels_in_data:
@@ -340,9 +364,11 @@ def convert_data(root_path, datastore_factory: Callable | None = None, *, codebo
             stage = np.asarray([np.round(positions[t, 0], 2), np.round(positions[t, 1], 2),
                                 np.round(positions[t, 2], 2)], dtype=np.float32)
             tile_id, round_id = store.tile_ids[t], store.round_ids[r]
-            store.set_corrected_image(np.squeeze(raw[0]).astype(np.uint16), tile=tile_id, round=round_id,
-                                      wavelengths_um=(ex[0], em[0]))
-            store.set_stage_position_zyx_um(tile_id, stage, identity_px, round=r)
+            store.save_local_corrected_image(np.squeeze(raw[0]).astype(np.uint16), tile=tile_id, psf_idx=0,
+                                             gain_correction=True, hotpixel_correction=False, shading_correction=False,
+                                             round=round_id)
+            store.save_local_stage_position_zyx_um(stage, identity_px, tile=tile_id, round=round_id)
+            store.save_local_wavelengths_um((ex[0], em[0]), tile=tile_id, round=round_id)
             for ch in (1, 2):
                 image = np.squeeze(raw[ch]).astype(np.uint16)
                 if synthetic_chromatic_aberration:
@@ -352,8 +378,10 @@ def convert_data(root_path, datastore_factory: Callable | None = None, *, codebo
                         synthetic_chromatic_max_z_shifts_px)
                 bit = int(experiment_order[r, ch]) - 1
                 bit_id = store.bit_ids[bit]
-                store.set_corrected_image(image, tile=tile_id, bit=bit_id, wavelengths_um=(ex[ch], em[ch]))
-                store.set_round_linker(tile_id, bit_id, r + 1)
+                store.save_local_corrected_image(image, tile=tile_id, psf_idx=ch, gain_correction=True,
+                                                 hotpixel_correction=False, shading_correction=False, bit=bit_id)
+                store.save_local_wavelengths_um((ex[ch], em[ch]), tile=tile_id, bit=bit_id)   # the bit's round link
+                # comes from the experiment order the store was created with (initialize_tile in the reference)
     state = dict(store.datastore_state or {})
     state.update({"Corrected": True})
     store.datastore_state = state

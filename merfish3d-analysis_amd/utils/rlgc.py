@@ -424,13 +424,14 @@ def rlgc_device(
     injected_splits=None,
     image_is_u16: bool | None = None,
     out=None,
-    profile: bool = False,
+    profile: bool | str = False,
 ):
     """Device-resident RLGC: torch tensors in HBM in, float32 tensor in HBM out.
 
     ``image`` is ``[Z,Y,X]`` float32, or int16/uint16 storage holding uint16
     counts (``image_is_u16``); ``psf`` float32 ``[Zp,Yp,Xp]``.  Returns
-    ``(deconvolved float32[Z,Y,X], RLGCInfo)``.
+    ``(deconvolved float32[Z,Y,X], RLGCInfo)``.  ``profile``: ``True`` records HIP events around every FFT pass
+    (``conv_ms_total``, ``kernel_ms``, ``loop_ms``), ``"loop"`` only the two around the iteration loop (``loop_ms``).
     """
     import ctypes
 
@@ -464,7 +465,7 @@ def rlgc_device(
         seed=int(secrets.randbits(63) if rng_seed is None else rng_seed) & 0xFFFFFFFFFFFFFFFF,
         normalize_psf=int(bool(normalize_psf)),
         max_iterations=int(max_iterations),
-        profile=int(bool(profile)),
+        profile=2 if profile == "loop" else int(bool(profile)),
     )
     n_inj = 0
     inj_ptr = None

@@ -260,6 +260,30 @@ def test_support_pruned_convolutions_equal_the_full_ones(shape, psf_shape, monke
     assert _rel_err(out, ref) < 2e-5
 
 
+def test_update_pass_chained_into_the_next_forward_transform_changes_nothing(monkeypatch):
+    """Lateral size 2187 (the only one with the chained build): the update pass that writes the next iteration's X
+    forward transform over the spectrum rows it has read (M3D_RLGC_CHAIN_UPDATE=1, the default) against the unchained
+    sequence - same iterations, same traces, the same volume to float32 rounding of one transform."""
+    rl = pkg("utils.rlgc")
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    shape = (22, 2140, 2140)       # + the PSF halo and FFT smoothing = 2187 laterally, 32 planes (register Z pass)
+    img = torch.poisson(torch.rand(shape, device=DEV, generator=gen) * 150 + 40, generator=gen).to(torch.uint16)
+    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (9, 47, 47)], indexing="ij")
+    psf = torch.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2)).float()
+    out = {}
+    for chain in ("0", "1"):
+        monkeypatch.setenv("M3D_RLGC_CHAIN_UPDATE", chain)
+        o, info = rl.rlgc_device(img, psf, max_iterations=6, rng_seed=11)
+        out[chain] = (o.clone(), info)
+    a, b = out["0"], out["1"]
+    assert tuple(a[1].padded_shape) == (32, 2187, 2187), a[1].padded_shape
+    assert (a[1].iterations, a[1].stop_reason) == (b[1].iterations, b[1].stop_reason)
+    np.testing.assert_allclose(a[1].kld_split1, b[1].kld_split1, rtol=1e-5, atol=1e-8)
+    err = float((a[0] - b[0]).abs().max() / a[0].abs().max())
+    assert err < 2e-5, err
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+
+
 def test_setup_is_reused_for_the_same_psf_and_rebuilt_for_another(monkeypatch):
     """OTF / update_norm stay in the plan's workspace between runs (a tile's bits share their PSF): reusing
     them must give the bits a fresh setup gives, and a different PSF must not pick up stale volumes."""

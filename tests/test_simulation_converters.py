@@ -5,7 +5,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import pkg
+from conftest import GOLDEN, pkg
 
 
 @pytest.fixture(scope="module")
@@ -127,3 +127,24 @@ def test_calculate_f1_conventions(sim, tmp_path):
     assert sim.calculate_F1(store, gt, search_radius=0.05, decoded_spots=swapped)["F1 Score"] < 0.2
     unshifted = decoded.assign(global_z=decoded["global_z"] + dz / 2)
     assert sim.calculate_F1(store, gt, search_radius=0.05, decoded_spots=unshifted)["F1 Score"] < 0.2
+
+
+def test_tiff_codec_against_the_real_tifffile(tmp_path):
+    """tests/golden/tiff_codec.npz (tests/golden/make_golden_tiff.py, tifffile 2021.7.2 of the image's conda Python):
+    ``read_tiff`` reads what tifffile wrote - including the RGB(A)-planar pages tifffile chooses on its own for a
+    leading axis of length 3 or 4, which is the (channel, z, y, x) stack ``convert_simulation`` writes when z is 3 or
+    4 - and ``write_tiff`` still produces, byte for byte, the files tifffile read back to the same arrays."""
+    sim = pkg("simulation")
+    g = np.load(GOLDEN / "tiff_codec.npz", allow_pickle=False)
+    assert str(g["tifffile_version"]).startswith("2021.")
+    for name in [str(c) for c in g["cases"]]:
+        want = g["array_" + name]
+        src = tmp_path / f"tifffile_{name}.tif"
+        g["tifffile_file_" + name].tofile(src)
+        got = sim.read_tiff(src)
+        assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), name
+        dst = tmp_path / f"ours_{name}.tif"
+        sim.write_tiff(dst, want)
+        assert np.array_equal(np.fromfile(dst, dtype=np.uint8), g["ours_file_" + name]), name
+        back = sim.read_tiff(dst)
+        assert back.dtype == want.dtype and back.shape == want.shape and np.array_equal(back, want), name
