@@ -209,3 +209,18 @@ def test_phase_correlation_matches_scikit_image_golden(golden):
         wrap = lambda d: (d + n / 2) % n - n / 2
         assert np.abs(wrap(full - s[f"shift_{i}_up10"])).max() <= 0.1 + 1e-5
         assert np.abs(wrap(full + s[f"true_{i}"])).max() <= 0.2 + 1e-5
+
+
+def test_affine_plus_flow_warp_restatement_matches_the_reference_run(golden):
+    """tests/oracle_pipeline.py::warp_with_affine_and_flow (multiview_registration.py:905-1131) against the reference
+    run behind registration.npz: constant boundary with a real affine and anisotropic spacing, and the estimator's
+    identity / unit-spacing / nearest form."""
+    import oracle_pipeline as op
+
+    g = golden("registration")
+    a = op.warp_with_affine_and_flow(g["volume"], g["transform"], tuple(g["spacing"]), g["volume"].shape, g["flow"],
+                                     g["flow_stride"], g["flow_box_start"])
+    np.testing.assert_allclose(a, g["flow_warp_constant"], rtol=1e-5, atol=2e-3)
+    b = op.warp_with_affine_and_flow(g["volume"], np.eye(4, dtype=np.float32), (1.0, 1.0, 1.0), g["volume"].shape,
+                                     g["flow"], g["flow_stride"], g["flow_box_start"], mode="nearest")
+    np.testing.assert_allclose(b, g["flow_warp_nearest"], rtol=1e-5, atol=2e-3)
