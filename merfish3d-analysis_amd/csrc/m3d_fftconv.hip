@@ -1135,16 +1135,23 @@ __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, Conv
 // index arithmetic on run-time geometry (k_y_pass: 821 scalar + ~250 integer vector instructions around ~350
 // floating-point ones).  For the headline geometry the whole pass is compiled with every extent, stride, radix and
 // chunk size as a constant: the stage loops unroll, divisions become shifts and immediates.
-template <int R, bool INV, int N, int M, int TWc, int NT_>
+template <int R, bool INV, int N, int M, int TWc, int NT_, int CPT_ = 1>
 __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__restrict__ tw, int tid)
 {
     // four interleaved transforms (TW = 4): element k of transform b at data[k * TW + b]
     constexpr int sub = M / R, per_fft = N / R, twstep = N / M, step = sub * TWc;
-    // one (butterfly, column) pair per work item: four times the parallelism for the price of recomputing the twiddles
-    // per column (the pass waits on LDS latency, 71 % of wave time, not on instruction issue)
+    // One (butterfly, column group) per work item.  CPT = 1: every column its own item (four times the items, twiddles
+    // recomputed per column; round 2).  CPT = 2: two adjacent columns per item - twiddles and index arithmetic shared,
+    // and the two columns of a row are 16 contiguous bytes, one ds_read_b128 / ds_write_b128 instead of two 8-byte
+    // accesses; same operations, same order, same twiddle values per element.  Measured (round 3,
+    // profiles/r03_y_pass_columns.txt): the inverse pass, whose item fits 62 registers, gains 4 % (731 -> 700 us); the
+    // forward passes need 80-88 registers for it (twiddles applied after the butterfly keep both columns live), which
+    // costs the second 1024-thread block per CU (spills at 64: 2.7 ms) or, with 768-thread blocks, gives back what the
+    // saved instructions bring (647 vs 655 us; the mirror pass 570 vs 483 us) - they stay at one column per item.
+    constexpr int CPT = (TWc % CPT_ == 0) ? CPT_ : 1, GR = TWc / CPT;
 #pragma unroll 1
-    for (int t = tid; t < per_fft * TWc; t += NT_) {
-        const int c = t & (TWc - 1), it = t / TWc;
+    for (int t = tid; t < per_fft * GR; t += NT_) {
+        const int c = (t % GR) * CPT, it = t / GR;
         const int blk = it / sub, j = it - blk * sub;
         float2 w[R];
         const int j1 = j * twstep;
@@ -1163,20 +1170,42 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
             if constexpr (R >= 4) w[3] = cmul(w[1], w[2]);
         }
         float2 *p = data + (blk * M + j) * TWc + c;
-        float2 v[R];
+        float2 v[CPT][R];
+        if constexpr (CPT == 2) {
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = p[q * step];
-        if (INV) {
-#pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul_conj(v[q], w[q]);
-            dft_r<R, true>(v);
+            for (int q = 0; q < R; ++q) {
+                const float4 two = *(const float4 *)(p + q * step);
+                v[0][q] = make_float2(two.x, two.y);
+                v[1][q] = make_float2(two.z, two.w);
+            }
         } else {
-            dft_r<R, false>(v);
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmul(v[q], w[q]);
+            for (int q = 0; q < R; ++q)
+#pragma unroll
+                for (int u = 0; u < CPT; ++u) v[u][q] = p[q * step + u];
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) p[q * step] = v[q];
+        for (int u = 0; u < CPT; ++u) {
+            if (INV) {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[u][q] = cmul_conj(v[u][q], w[q]);
+                dft_r<R, true>(v[u]);
+            } else {
+                dft_r<R, false>(v[u]);
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[u][q] = cmul(v[u][q], w[q]);
+            }
+        }
+        if constexpr (CPT == 2) {
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+                *(float4 *)(p + q * step) = make_float4(v[0][q].x, v[0][q].y, v[1][q].x, v[1][q].y);
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q)
+#pragma unroll
+                for (int u = 0; u < CPT; ++u) p[q * step + u] = v[u][q];
+        }
     }
 }
 
@@ -1223,14 +1252,14 @@ __global__ __launch_bounds__(NT_) void k_y_pass_static(float2 *__restrict__ spec
         }
     } else {
         if constexpr (R3 > 1) {
-            y_stage_static<R3, true, YP, R3, TWc, NT_>(lds_ys, tw, tid);
+            y_stage_static<R3, true, YP, R3, TWc, NT_, 2>(lds_ys, tw, tid);
             __syncthreads();
         }
-        y_stage_static<R2, true, YP, R3 * R2, TWc, NT_>(lds_ys, tw, tid);
+        y_stage_static<R2, true, YP, R3 * R2, TWc, NT_, 2>(lds_ys, tw, tid);
         __syncthreads();
-        y_stage_static<R1, true, YP, R3 * R2 * R1, TWc, NT_>(lds_ys, tw, tid);
+        y_stage_static<R1, true, YP, R3 * R2 * R1, TWc, NT_, 2>(lds_ys, tw, tid);
         __syncthreads();
-        y_stage_static<R0, true, YP, YP, TWc, NT_>(lds_ys, tw, tid);
+        y_stage_static<R0, true, YP, YP, TWc, NT_, 2>(lds_ys, tw, tid);
         __syncthreads();
     }
     for (int i = slo / 2 + tid; i < shi / 2; i += NT_) *(float4 *)(pl + elem(i)) = l4[i];
@@ -1730,8 +1759,8 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && (p->ythreads == 768 || p->ythreads == 1024) &&
                   p->gy == 4 && p->ay.nstages == 4 && p->ay.radix[0] == 9 && p->ay.radix[1] == 9 &&
                   p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 1 : 0;
-    // the static Y kernels spread (butterfly, column) pairs over the threads: 972 pairs in the radix-9 stages, one
-    // round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
+    // the static Y kernels spread (butterfly, column group) items over the threads: 972 (forward) / 486 (inverse) items
+    // in the radix-9 stages, one round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
     if (p->ystatic && getenv("M3D_FFT_YT") == nullptr) p->ythreads = 1024;
     p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
                   p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&

@@ -11,7 +11,18 @@ Z, Y, X = (int(v) for v in sys.argv[1:4])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
-img = torch.poisson(torch.rand((Z, Y, X), device=dev, generator=g) * 200 + 50, generator=g).to(torch.uint16)
+if __import__("os").environ.get("M3D_PROBE_IMAGE", "noise") == "emitters":
+    # the bench's kind of image: background 100, blurred point emitters of 300-900 peak counts, shot noise
+    kernels = importlib.import_module("merfish3d-analysis_amd.kernels")
+    n_em = max(50, Z * Y * X // 3400)
+    vol = torch.zeros((Z, Y, X), device=dev)
+    idx = torch.randint(0, Z * Y * X, (n_em,), device=dev, generator=g)
+    vol.view(-1).index_put_((idx,), (torch.rand(n_em, device=dev, generator=g) * 600 + 300) / 0.0138, accumulate=True)
+    kernels.gaussian_lowpass(vol, (1.8, 1.6, 1.6), True, out=vol)
+    img = torch.poisson(vol + 100.0, generator=g).clamp_(0, 65535).to(torch.uint16)
+    del vol
+else:
+    img = torch.poisson(torch.rand((Z, Y, X), device=dev, generator=g) * 200 + 50, generator=g).to(torch.uint16)
 pz = min(64, Z)
 zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=dev) - n // 2 for n in (pz, 51, 51)], indexing="ij")
 psf = torch.exp(-0.5 * ((zz / 3.0) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2))

@@ -65,8 +65,9 @@ def run_cell(name: str, work: Path) -> dict:
                 status[rid] = [md.get("status"), int(md.get("valid_flow_vectors") or 0)]
                 progress(f"sofima {rid}: {status[rid]}")
             out["sofima_status"] = status
-        res = op.oracle_decode_and_score(store, gt, op.CELLS[name]["radius"])
-        out[mode] = {k: (float(v) if isinstance(v, (float, np.floating)) else int(v)) for k, v in res.items()}
+        res = op.oracle_decode_and_score(store, gt, op.CELLS[name]["radius"], op.CELLS[name]["decode"])
+        out[mode] = {k: (float(v) if isinstance(v, (float, np.floating)) else (int(v) if isinstance(v, (int, np.integer))
+                                                                                  else v)) for k, v in res.items()}
         progress(f"{mode}: {out[mode]}")
         if mode == "affine":
             t = store.tile_ids[0]
@@ -85,9 +86,10 @@ def main() -> None:
     with tempfile.TemporaryDirectory(prefix="m3d_f1_matrix_") as work:
         for name in cells:
             results[name] = run_cell(name, Path(work))
-            results["_meta"] = {"shape": list(op.SHAPE), "decode": {k: (list(v) if isinstance(v, tuple) else v)
-                                                                    for k, v in op.DECODE_KW.items()},
+            results["_meta"] = {"shape": list(op.SHAPE),
                                 "cells": {k: {"dz": c["dz"], "radius": c["radius"], "seed": c["seed"],
+                                              "decode": {a: (list(b) if isinstance(b, tuple) else b)
+                                                         for a, b in c["decode"].items()},
                                               "shifts": [list(s) for s in c["shifts"]]} for k, c in op.CELLS.items()}}
             path.write_text(json.dumps(results, indent=1, sort_keys=True))
     print("wrote", path)

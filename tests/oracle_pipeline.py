@@ -30,21 +30,24 @@ from oracle import ccl_ref, decode_ref, registration_ref, rlgc_ref, sofima_ref
 
 # the F1 matrix of the reference's acceptance test (tests/test_simulation_example_pipeline.py:48-52, 1244-1318): axial
 # spacing -> F1 search radius; each cell is run affine-only and with the SOFIMA residual flow
+# decode settings per cell as the reference's matrix chooses them (tests/test_simulation_example_pipeline.py:39-47):
+# magnitude threshold (0.9, 10) for Nyquist-sampled 3-D data, (0.7, 10) / (0.2, 10) for per-plane decoding at 3 x / 5 x
+# the Nyquist step, minimum pixels 7 in 2-D.  In 3-D the reference's 28 voxels is sized for its real PSF; the
+# synthetic spots here (sigma 1.2 x 1.5 x 1.5 px) cover fewer: 9.
 CELLS = {
-    "dz0.315": dict(dz=0.315, radius=1.0, seed=21,
+    "dz0.315": dict(dz=0.315, radius=1.0, seed=21, decode=dict(minimum_pixels=9, magnitude_threshold=(0.9, 10.0)),
                     # lateral shifts that round to 1..4 px: the range bench config 3 draws and the one in which
                     # phase_cross_correlation(disambiguate=True) meets its three-sample corner tiles
                     shifts=[(0, 0, 0), (0.4, 2.6, -3.2), (-0.3, -1.4, 3.7), (0.2, 3.3, 1.8), (0.0, -2.9, -3.6),
                             (0.5, 1.2, 3.9), (-0.4, -3.8, -1.6), (0.1, 2.9, -2.2)]),
-    "dz1.0": dict(dz=1.0, radius=1.0, seed=22,
+    "dz1.0": dict(dz=1.0, radius=1.0, seed=22, decode=dict(minimum_pixels=7, magnitude_threshold=(0.7, 10.0)),
                   shifts=[(0, 0, 0), (0.3, 6.4, -7.1), (-0.2, -7.7, 6.2), (0.2, 8.6, 5.8), (0.0, -6.9, -8.4),
                           (0.3, 5.2, 9.3), (-0.3, -8.8, -5.6), (0.1, 6.9, -7.7)]),
-    "dz1.5": dict(dz=1.5, radius=1.5, seed=23,
+    "dz1.5": dict(dz=1.5, radius=1.5, seed=23, decode=dict(minimum_pixels=7, magnitude_threshold=(0.2, 10.0)),
                   shifts=[(0, 0, 0), (0.2, 5.4, -6.1), (-0.2, -6.7, 5.2), (0.1, 7.6, 4.8), (0.0, -5.9, -7.4),
                           (0.2, 4.2, 8.3), (-0.2, -7.8, -4.6), (0.1, 5.9, -6.7)]),
 }
 SHAPE = (16, 256, 256)
-DECODE_KW = dict(minimum_pixels=9, magnitude_threshold=(0.9, 10.0))
 
 
 def make_cell(root, name):
@@ -291,17 +294,30 @@ def _oracle_decoder_class():
     return OracleDecoder
 
 
-def oracle_decode_and_score(store, gt, radius: float) -> dict:
+def oracle_decode_and_score(store, gt, radius: float, decode_kw: dict) -> dict:
     """optimize_normalization_by_decoding (one tile, three iterations: the simulation CLI's setting,
     cli/statphysbio_simulation/pixeldecode.py:273-281) -> decode_all_tiles -> calculate_F1, all on the CPU."""
     sim = pkg("simulation")
     dec = _oracle_decoder_class()(store, merfish_bits=16, num_gpus=1, verbose=0)
-    dec.optimize_normalization_by_decoding(n_random_tiles=1, n_iterations=3, **DECODE_KW)
-    dec.decode_all_tiles(assign_to_cells=False, normalization_method="iterative", **DECODE_KW)
-    return sim.calculate_F1(store, gt, search_radius=radius)
+    dec.optimize_normalization_by_decoding(n_random_tiles=1, n_iterations=3, **decode_kw)
+    dec.decode_all_tiles(assign_to_cells=False, normalization_method="iterative", **decode_kw)
+    return {**sim.calculate_F1(store, gt, search_radius=radius), **_details(store, dec)}
 
 
-def hip_pipeline_score(store, gt, radius: float, deformable: bool) -> dict:
+def _details(store, dec) -> dict:
+    """What the F1 rests on, for diagnosis when two pipelines drift apart: transcripts before and after the
+    blank-fraction filter, the filter's threshold, the iterative normalisation vectors."""
+    norm, bkd = store.load_decode_normalization_vectors(None, "iterative")
+    diag = getattr(dec, "_blank_fraction_filter_results", {}) or {}
+    scalars = {k: (float(v) if isinstance(v, (float, np.floating)) else int(v)) for k, v in diag.items()
+               if isinstance(v, (float, int, np.floating, np.integer)) and not isinstance(v, bool)}
+    return {"decoded_before_filter": int(len(dec._df_barcodes_loaded)),
+            "decoded_after_filter": int(len(dec._df_filtered_barcodes)),
+            "filter": scalars, "normalization": np.round(np.asarray(norm, dtype=float), 1).tolist(),
+            "background": np.round(np.asarray(bkd, dtype=float), 1).tolist()}
+
+
+def hip_pipeline_score(store, gt, radius: float, deformable: bool, decode_kw: dict) -> dict:
     """The same pipeline through the package's operators on the GPU."""
     sim, DR, PD = pkg("simulation"), pkg("DataRegistration"), pkg("PixelDecoder")
     reg = DR.DataRegistration(store, decon_fiducial=True, decon_readout=True,
@@ -309,6 +325,6 @@ def hip_pipeline_score(store, gt, radius: float, deformable: bool) -> dict:
                               feature_predictor=predictor)
     reg.register_all_tiles()
     dec = PD.PixelDecoder(store, merfish_bits=16, num_gpus=1, verbose=0)
-    dec.optimize_normalization_by_decoding(n_random_tiles=1, n_iterations=3, **DECODE_KW)
-    dec.decode_all_tiles(assign_to_cells=False, normalization_method="iterative", **DECODE_KW)
-    return sim.calculate_F1(store, gt, search_radius=radius)
+    dec.optimize_normalization_by_decoding(n_random_tiles=1, n_iterations=3, **decode_kw)
+    dec.decode_all_tiles(assign_to_cells=False, normalization_method="iterative", **decode_kw)
+    return {**sim.calculate_F1(store, gt, search_radius=radius), **_details(store, dec)}

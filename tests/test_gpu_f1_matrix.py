@@ -34,7 +34,7 @@ def test_f1_of_the_hip_pipeline_stands_with_the_oracle_pipelines(cell, tmp_path)
     scores = {}
     for mode, deformable in (("affine", False), ("sofima", True)):
         store = copy.deepcopy(base)
-        scores[mode] = op.hip_pipeline_score(store, gt, op.CELLS[cell]["radius"], deformable)
+        scores[mode] = op.hip_pipeline_score(store, gt, op.CELLS[cell]["radius"], deformable, op.CELLS[cell]["decode"])
         if mode == "affine":
             t, sp = store.tile_ids[0], np.asarray(store.voxel_size_zyx_um)
             found = np.asarray([np.asarray(store.load_local_round_transform_zyx_um(t, r))[:3, 3] / sp
