@@ -54,7 +54,7 @@ def make_cell(root, name):
     """The cell's dataset in the statphysbio on-disk layout -> (in-memory datastore, ground-truth table)."""
     sim = pkg("simulation")
     c = CELLS[name]
-    path = sim.make_simulation(root / name, shape_zyx=SHAPE, n_rna=1000, n_beads=700, round_shifts_px=c["shifts"],
+    path = sim.make_simulation(root / name, shape_zyx=SHAPE, n_rna=3000, n_beads=700, round_shifts_px=c["shifts"],
                                deformation_px=1.2, seed=c["seed"], voxel_zyx_um=(c["dz"], 0.098, 0.098))
     store = sim.convert_data(sim.convert_simulation(path))
     t = store.tile_ids[0]
