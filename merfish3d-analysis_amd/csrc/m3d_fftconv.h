@@ -5,6 +5,8 @@
 
 #include <vector>
 
+#include "m3d_binom.h"
+
 namespace m3d {
 
 // Optional HIP-event log (bench.py roofline).  mark(kind) drops an event on the stream; the time since
@@ -109,10 +111,35 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
 bool fftconv_real_otf_supported(const FftConvPlan *p);
 int fftconv_otf_abs2(const FftConvPlan *p, const float2 *otf, float *out, void *stream);
 
+// The split stage of an RLGC iteration fused between two convolutions (rlgc.py:619-672): the X inverse pass of the
+// forward-model convolution (Hu on the core) does not store Hu but runs k_split_ratio's arithmetic on the registers
+// of its last stage - binomial photon split, the three KL sums, the two ratio volumes - and hands both ratio rows
+// straight to the X forward transforms of the two ratio convolutions.  Hu, ratio1 and ratio2 never exist in HBM (38 ->
+// 14 bytes per core voxel and three launches less per iteration).  `spec_hu` holds the half-spectrum rows of Hu (after
+// its inverse Y pass) and receives the rows of ratio2's X transform in place; `spec_r1` receives ratio1's.
+struct SplitPartial {  // one per workgroup; summed in a fixed order by the caller
+    double A, Bim, B1, B2, Tim, T1, T2;
+};
+struct SplitArgs {
+    const void *image;      // the observed image [core.nz][core.ny][core.nx], uint16 or float32
+    int image_is_u16;
+    const float *injected;  // optional split1 volume of the same shape (parity hook), else nullptr
+    uint32_t iteration;
+    uint64_t seed;
+    BinomTables tables;
+    SplitPartial *partial;  // fftconv_split_chain_blocks() records
+};
+bool fftconv_split_chain_supported(const FftConvPlan *p);
+int64_t fftconv_split_chain_blocks(const FftConvPlan *p, const ConvBox *core);
+int fftconv_split_chain(const FftConvPlan *p, float2 *spec_hu, float2 *spec_r1, const ConvBox *core,
+                        const SplitArgs *args, void *stream, EventLog *log);
+
 // fftconv_to_rows for two inputs that take the same transfer function (the two HTratio convolutions of an RLGC
 // iteration): the Z pass of both runs as one launch that reads each OTF line from HBM once.
+// x_forward_done: the spectra already hold the X transforms of the inputs' rows (fftconv_split_chain); src1 / src2 unused.
 int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *src2, const float2 *otf, int mode,
-                         float2 *spec1, float2 *spec2, void *stream, EventLog *log, const ConvBox *in_box);
+                         float2 *spec1, float2 *spec2, void *stream, EventLog *log, const ConvBox *in_box,
+                         bool x_forward_done = false);
 
 // fft_conv without its X inverse pass: afterwards `spec` holds the half spectrum along x of every
 // (z, y) row of the result (rows of `out_box` only).

@@ -1086,6 +1086,185 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     }
 }
 
+// ---------------------------------------------------------------- X inverse of Hu + split + two X forward transforms
+// One row pair (y, y + 1) of one core plane per workgroup; static geometry (2187 = 9 * 9 * 3 * 9) only.  LDS: two
+// rows of N complex values - T carries the packed inverse transform of the pair and then ratio1's packed forward
+// transform, P ratio2's.  The split arithmetic is k_split_ratio's (m3d_rlgc.hip), operation for operation.
+template <typename T>
+__device__ __forceinline__ float load_count(const T *p, int64_t i)
+{
+    return (float)p[i];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2, float2 *__restrict__ spec1, ConvGeo g_,
+                                                              AxisPlan ax, m3d::SplitArgs sa)
+{
+#pragma clang fp contract(off)
+    extern __shared__ float2 lds_sp[];
+    __shared__ double smd[4][7];
+    constexpr int N = 2187, S = 243, I = 122;
+    const ConvGeo g = static_geo<2187>(g_);
+    const int tid = threadIdx.x;
+    const int y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
+    const int yg0 = (g.out.y0 / 4) * 4;  // the pairing of the other X passes (four rows per group, pairs inside)
+    const int pairs = (y_hi - yg0 + 1) / 2;
+    const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
+    // workgroups b and b + 8 share an XCD: give them the two row pairs that share 128-byte lines (see the dual pass)
+    const int item = (g.xcdpair && b < (nblk & ~15)) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
+    const int z = g.out.z0 + item / pairs, ya = yg0 + (item % pairs) * 2;
+    const bool va = ya >= g.out.y0 && ya < y_hi, vb = ya + 1 >= g.out.y0 && ya + 1 < y_hi;
+    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    const bool pair_live = tid < 2 * I;
+    int pu1 = 0, pu2 = 0;
+    if (pair_live) {
+        pu1 = ax.pos[kp] / 9;
+        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / 9;
+    }
+    const int64_t zterm = (int64_t)z * g.plane;
+    if (tid < I) {
+        float2 Av[9], Bv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Av[i] = Bv[i] = make_float2(0.f, 0.f);
+        if (va || vb) {  // the first / last item of a plane may lie wholly outside the box (the pairing starts on a
+                         // multiple of four rows): nothing is read for it and nothing stored
+            const int yac = va ? ya : ya + 1, ybc = vb ? ya + 1 : yac;
+            int rows_c, off[9];
+            const int rba = row_base(g, yac, rows_c), rbb = rba + ((ybc - yac) << g.lTW);
+            pair_offsets(g, S, kp, rows_c, off);
+            const float2 *sa_ = spec2 + zterm + rba, *sb_ = spec2 + zterm + rbb;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                Av[i] = sa_[off[i]];
+                Bv[i] = sb_[off[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (!va) Av[i] = make_float2(0.f, 0.f);
+                if (!vb) Bv[i] = make_float2(0.f, 0.f);
+            }
+        }
+        inverse_pair_merge(lds_sp, S, N, kp, pu1, pu2, Av, Bv);
+    }
+    __syncthreads();
+    middle_inverse<1, 2187>(lds_sp, ax, 1, N, tid, 256, g.GX);
+    const float eps = 1e-4f;
+    float sums[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // A, Bim, B1, B2, Tim, T1, T2 of this thread's 18 voxels
+    if (tid < S) {
+        const T *image = (const T *)sa.image;
+        const int64_t plane0 = (int64_t)(z - g.out.z0) * g.out.ny;
+        // counts (and injected splits) of both rows: requested before the last inverse stage; rows and columns outside
+        // the box are clamped into it (their values are not used)
+        float cnt[2][9], inj[2][9];
+        int64_t irows[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            irows[r] = (plane0 + min(max(ya + r - g.out.y0, 0), g.out.ny - 1)) * g.out.nx;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int xi = min(max(tid + S * q - g.out.x0, 0), g.out.nx - 1);
+                cnt[r][q] = load_count(image, irows[r] + xi);
+                inj[r][q] = sa.injected ? sa.injected[irows[r] + xi] : 0.0f;
+            }
+        }
+        float2 w[9];
+        edge_twiddles(w, ax.tw, tid);
+        float2 v[9];  // (Hu of row ya, Hu of row ya + 1) at x = tid + S q
+        const float2 *row = lds_sp + tid;
+        v[0] = row[0];
+#pragma unroll
+        for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
+        dft9<true>(v);
+        float2 p1[9], p2[9];  // (ratio1 of row ya, of row ya + 1), the same for ratio2; zero outside the core
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p1[q] = p2[q] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(r ? vb : va)) continue;
+            const int64_t irow = irows[r];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int x = tid + S * q;
+                if (x < g.out.x0 || x >= x_hi) continue;
+                const float h = r ? v[q].y : v[q].x;
+                const float val = cnt[r][q];
+                float s1;
+                if (sa.injected) {
+                    s1 = inj[r][q];
+                } else {
+                    const float vt = val > 0.0f ? val : 0.0f;
+                    const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);  // astype(int64) truncation, rlgc.py:619
+                    s1 = (float)m3d::binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + (x - g.out.x0)), sa.iteration,
+                                                                      sa.seed, sa.tables);
+                }
+                const float s2 = val - s1;
+                const float a = h + eps;  // kl_div, rlgc.py:401-412, as raw sums
+                const float bim = val + eps, b1 = s1 + eps, b2 = s2 + eps;
+                sums[0] += a;
+                sums[1] += bim;
+                sums[2] += b1;
+                sums[3] += b2;
+                if (a > 0.0f) {
+                    const float la = __builtin_amdgcn_logf(a);
+                    sums[4] += a * (la - __builtin_amdgcn_logf(bim));
+                    sums[5] += a * (la - __builtin_amdgcn_logf(b1));
+                    sums[6] += a * (la - __builtin_amdgcn_logf(b2));
+                }
+                const float inv = m3d::rn_div(1.0f, 0.5f * (h + 1e-12f));  // rlgc.py:654-668
+                if (r == 0) {
+                    p1[q].x = s1 * inv;
+                    p2[q].x = s2 * inv;
+                } else {
+                    p1[q].y = s1 * inv;
+                    p2[q].y = s2 * inv;
+                }
+            }
+        }
+        {   // first forward stage of both packed ratio rows, into the slots this thread read (T) and their twins (P)
+#pragma clang fp contract(fast)
+            dft9<false>(p1);
+            float2 *o1 = lds_sp + tid;
+            o1[0] = p1[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) o1[S * q] = cmul(p1[q], w[q]);
+            dft9<false>(p2);
+            float2 *o2 = lds_sp + N + tid;
+            o2[0] = p2[0];
+#pragma unroll
+            for (int q = 1; q < 9; ++q) o2[S * q] = cmul(p2[q], w[q]);
+        }
+    }
+    // the seven sums: wave shuffles, then four values per sum through LDS; they ride the barrier the transforms need
+    {
+        double d[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) d[k] = m3d::wave_sum((double)sums[k]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) smd[tid >> 6][k] = d[k];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double ln2 = 0.69314718055994530942;
+        double t[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t[k] = ((smd[0][k] + smd[1][k]) + smd[2][k]) + smd[3][k];
+        m3d::SplitPartial out = {t[0], t[1], t[2], t[3], t[4] * ln2, t[5] * ln2, t[6] * ln2};
+        sa.partial[blockIdx.x] = out;
+    }
+    {
+#pragma clang fp contract(fast)
+        middle_forward<1, 2187>(lds_sp, ax, 2, N, tid, 256, g.GX);
+        if (pair_live) {
+            float2 c1[9], c2[9];
+            forward_pair_load(lds_sp + pbi * N, pu1, pu2, c1, c2);
+            forward_pair_emit<false>(c1, c2, g, S, kp, pbi ? spec2 : spec1, zterm, ya, va, vb);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- Y pass (in place)
 template <bool INV, int RSET>
 __global__ __launch_bounds__(1024) void k_y_pass(float2 *__restrict__ spec, ConvGeo g, AxisPlan ay)
@@ -2068,19 +2247,23 @@ int fftconv_otf_abs2(const FftConvPlan *p, const float2 *otf, float *out, void *
 }
 
 int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *src2, const float2 *otf, int mode,
-                         float2 *spec1, float2 *spec2, void *stream, EventLog *log, const ConvBox *in_box)
+                         float2 *spec1, float2 *spec2, void *stream, EventLog *log, const ConvBox *in_box,
+                         bool x_forward_done)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (!src1 || !src2 || !spec1 || !spec2 || spec1 == spec2 || !box_ok(p, in_box)) return M3D_ERR_INVALID_ARG;
+    if ((!x_forward_done && (!src1 || !src2)) || !spec1 || !spec2 || spec1 == spec2 || !box_ok(p, in_box))
+        return M3D_ERR_INVALID_ARG;
     // one span of the event log: both X passes, then both Y passes (two launch_forward_xy calls would open a second
     // span in the middle and drop the first spectrum's Y pass from the attribution)
     ConvGeo g = geo_of(p, in_box, nullptr);
     g.zmirror = 0;
     const int groups = row_groups(p, g.in);
     if (log && log->mark(EventLog::kStart)) return M3D_ERR_HIP;
-    launch_x_forward(p, src1, spec1, g, groups, st);
-    launch_x_forward(p, src2, spec2, g, groups, st);
-    if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
+    if (!x_forward_done) {
+        launch_x_forward(p, src1, spec1, g, groups, st);
+        launch_x_forward(p, src2, spec2, g, groups, st);
+        if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
+    }
     launch_y_pass<false>(p, spec1, g, g.in.nz, st);
     launch_y_pass<false>(p, spec2, g, g.in.nz, st);
     M3D_KERNEL_CHECK();
@@ -2091,6 +2274,35 @@ int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *s
     launch_y_pass<true>(p, spec1, g, g.out.nz, st);
     launch_y_pass<true>(p, spec2, g, g.out.nz, st);
     if (log && log->mark(EventLog::kYI)) return M3D_ERR_HIP;
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+bool fftconv_split_chain_supported(const FftConvPlan *p) { return p && p->xstatic && p->TW == 4 && p->RB == 4; }
+
+int64_t fftconv_split_chain_blocks(const FftConvPlan *p, const ConvBox *core)
+{
+    if (!p || !core) return 0;
+    const int yg0 = (core->y0 / 4) * 4;
+    return (int64_t)core->nz * ((core->y0 + core->ny - yg0 + 1) / 2);
+}
+
+int fftconv_split_chain(const FftConvPlan *p, float2 *spec_hu, float2 *spec_r1, const ConvBox *core,
+                        const SplitArgs *args, void *stream, EventLog *log)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!fftconv_split_chain_supported(p)) return M3D_ERR_UNSUPPORTED;
+    if (!spec_hu || !spec_r1 || spec_hu == spec_r1 || !core || !box_ok(p, core) || !args || !args->image ||
+        !args->partial || !args->tables.thr)
+        return M3D_ERR_INVALID_ARG;
+    const ConvGeo g = geo_of(p, nullptr, core);
+    const dim3 grid((unsigned)fftconv_split_chain_blocks(p, core)), block(256);
+    const size_t lds = (size_t)2 * p->Xp * sizeof(float2);
+    if (args->image_is_u16)
+        hipLaunchKernelGGL(k_x_inverse_split_chain<uint16_t>, grid, block, lds, st, spec_hu, spec_r1, g, p->ax, *args);
+    else
+        hipLaunchKernelGGL(k_x_inverse_split_chain<float>, grid, block, lds, st, spec_hu, spec_r1, g, p->ax, *args);
+    if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
 }

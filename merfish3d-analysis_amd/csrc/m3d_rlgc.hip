@@ -298,6 +298,30 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
     }
 }
 
+// First level for the fused split kernel's one-partial-per-workgroup array (65 536 records at the headline size): block
+// b sums records b, b + gridDim.x, ... in a fixed order into record b of `out`; k_kl_finalize folds those.
+__global__ void k_kl_reduce(const KlPartial *__restrict__ partial, int n, KlPartial *__restrict__ out)
+{
+    __shared__ double sm[4];
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x + (int)gridDim.x * (int)threadIdx.x; i < n; i += (int)gridDim.x * (int)blockDim.x) {
+        const KlPartial p = partial[i];
+        v[0] += p.A;
+        v[1] += p.Bim;
+        v[2] += p.B1;
+        v[3] += p.B2;
+        v[4] += p.Tim;
+        v[5] += p.T1;
+        v[6] += p.T2;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = block_sum(v[k], sm);
+    if (threadIdx.x == 0) {
+        const KlPartial p = {v[0], v[1], v[2], v[3], v[4], v[5], v[6]};
+        out[blockIdx.x] = p;
+    }
+}
+
 __global__ void k_kl_finalize(const KlPartial *__restrict__ partial, int nblocks, Status *st)
 {
     __shared__ double sm[4];
@@ -974,20 +998,50 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
                        &dstat->mean, g.Np);
     M3D_KERNEL_CHECK();
     if (fused_tail) hipLaunchKernelGGL(k_arm_fused_reductions, dim3(1), dim3(kBlock), 0, st, cons_red, upd_red);
-    // ratio volumes: pad region stays zero for the whole run (only the core is rewritten)
-    M3D_HIP_CHECK(hipMemsetAsync(r1, 0, sizeof(float) * (size_t)g.Np, st));
-    M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
 
     // The update pass can hand the next forward-model convolution its X forward transform (ConvEpilogue::chain).
     const bool chain_update = fused_tail && m3d::fftconv_update_chain_supported(p->fc) &&
                               !(getenv("M3D_RLGC_CHAIN_UPDATE") && atoi(getenv("M3D_RLGC_CHAIN_UPDATE")) == 0);
     bool hu_x_ready = false;  // cbuf holds the X transforms of recon_cur's core rows
+    // The split stage can sit between the X inverse pass of the Hu convolution and the X forward passes of the two
+    // ratio convolutions (m3d::fftconv_split_chain): Hu and both ratio volumes then never reach HBM.  The per-workgroup
+    // KL partials of that kernel take the (then unused) ratio1 volume's place.
+    static_assert(sizeof(m3d::SplitPartial) == sizeof(KlPartial), "the split kernels share their partial-sum record");
+    const bool split_chain = fused_tail && prune && m3d::fftconv_split_chain_supported(p->fc) &&
+                             !(getenv("M3D_RLGC_CHAIN_SPLIT") && atoi(getenv("M3D_RLGC_CHAIN_SPLIT")) == 0) &&
+                             (size_t)m3d::fftconv_split_chain_blocks(p->fc, &core) * sizeof(KlPartial) <=
+                                 sizeof(float) * (size_t)g.Np;
+    if (!split_chain) {  // ratio volumes: pad region stays zero for the whole run (only the core is rewritten)
+        M3D_HIP_CHECK(hipMemsetAsync(r1, 0, sizeof(float) * (size_t)g.Np, st));
+        M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
+    }
     auto enqueue_forward = [&](int it) -> int {
+        const float *inj =
+            (injected && it < n_injected) ? injected + (size_t)it * (size_t)g.N : nullptr;
+        if (split_chain) {
+            ++elog.convolutions;
+            float2 *rows = nullptr, *cbuf2 = (float2 *)w2;
+            int rc3 = m3d::fftconv_to_rows(p->fc, recon_cur, otf, 0, cbuf, st, &elog, nullptr, &core, &core, cbuf2,
+                                           &rows, hu_x_ready);  // Hu up to its X inverse pass, rlgc.py:624
+            hu_x_ready = false;
+            if (rc3) return rc3;
+            if (rows != cbuf2) {
+                set_err("rlgc", "the mirrored forward-model convolution left its rows in an unexpected buffer");
+                return M3D_ERR_HIP;
+            }
+            KlPartial *big = (KlPartial *)r1;
+            const m3d::SplitArgs sa = {image, image_dtype == M3D_U16 ? 1 : 0, inj, (uint32_t)it, params->seed, binom,
+                                       (m3d::SplitPartial *)big};
+            if ((rc3 = m3d::fftconv_split_chain(p->fc, cbuf2, cbuf, &core, &sa, st, &elog))) return rc3;
+            hipLaunchKernelGGL(k_kl_reduce, dim3(128), dim3(kBlock), 0, st, big,
+                               (int)m3d::fftconv_split_chain_blocks(p->fc, &core), kl_part);
+            hipLaunchKernelGGL(k_kl_finalize, dim3(1), dim3(kBlock), 0, st, kl_part, 128, dstat);
+            M3D_KERNEL_CHECK();
+            return M3D_OK;
+        }
         int rc2 = conv(recon_cur, 0, hu, kOutCore | kMirrorIn, nullptr, hu_x_ready);  // Hu, rlgc.py:624 (core only)
         hu_x_ready = false;
         if (rc2) return rc2;
-        const float *inj =
-            (injected && it < n_injected) ? injected + (size_t)it * (size_t)g.N : nullptr;
         if (image_dtype == M3D_U16)
             hipLaunchKernelGGL(k_split_ratio<uint16_t>, dim3(g_core), rb, 0, st, hu,
                                (const uint16_t *)image, r1, r2, g, (uint32_t)it, params->seed,
@@ -1012,7 +1066,10 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             const m3d::ConvBox *in = &core;
             elog.convolutions += 2;
             static const bool zpair = !(getenv("M3D_RLGC_NO_ZPAIR") && atoi(getenv("M3D_RLGC_NO_ZPAIR")));
-            if (zpair) {
+            if (split_chain) {  // cbuf / cbuf2 hold the rows' X transforms of ratio1 / ratio2 already
+                if ((rc2 = m3d::fftconv_to_rows_pair(p->fc, nullptr, nullptr, otf, 1, cbuf, cbuf2, st, &elog, in, true)))
+                    return rc2;
+            } else if (zpair) {
                 if ((rc2 = m3d::fftconv_to_rows_pair(p->fc, r1, r2, otf, 1, cbuf, cbuf2, st, &elog, in))) return rc2;
             } else {
                 if ((rc2 = m3d::fftconv_to_rows(p->fc, r1, otf, 1, cbuf, st, &elog, in, nullptr, nullptr))) return rc2;

@@ -260,27 +260,45 @@ def test_support_pruned_convolutions_equal_the_full_ones(shape, psf_shape, monke
     assert _rel_err(out, ref) < 2e-5
 
 
-def test_update_pass_chained_into_the_next_forward_transform_changes_nothing(monkeypatch):
-    """Lateral size 2187 (the only one with the chained build): the update pass that writes the next iteration's X
-    forward transform over the spectrum rows it has read (M3D_RLGC_CHAIN_UPDATE=1, the default) against the unchained
-    sequence - same iterations, same traces, the same volume to float32 rounding of one transform."""
+def test_chained_passes_change_nothing(monkeypatch):
+    """Lateral size 2187 (the only one with the chained builds).  (a) The update pass that writes the next iteration's X
+    forward transform over the spectrum rows it has read (M3D_RLGC_CHAIN_UPDATE, default on) and (b) the split stage run
+    on the registers of the Hu convolution's X inverse pass and handed to the ratio convolutions' X forward transforms
+    (M3D_RLGC_CHAIN_SPLIT, default on: Hu and both ratio volumes never stored) against the unchained sequence - same
+    iterations, same stop, same KL traces, the same volume to the float32 rounding of a transform; also with injected
+    splits (the parity hook goes through the fused kernel too)."""
     rl = pkg("utils.rlgc")
     gen = torch.Generator(device=DEV).manual_seed(3)
     shape = (22, 2140, 2140)       # + the PSF halo and FFT smoothing = 2187 laterally, 32 planes (register Z pass)
     img = torch.poisson(torch.rand(shape, device=DEV, generator=gen) * 150 + 40, generator=gen).to(torch.uint16)
+    img[3, 100:140, 200:260] = 40000          # a saturated patch: table rows of the split's upper range
     zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (9, 47, 47)], indexing="ij")
     psf = torch.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2)).float()
     out = {}
-    for chain in ("0", "1"):
-        monkeypatch.setenv("M3D_RLGC_CHAIN_UPDATE", chain)
+    for update, split in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "1")):
+        monkeypatch.setenv("M3D_RLGC_CHAIN_UPDATE", update)
+        monkeypatch.setenv("M3D_RLGC_CHAIN_SPLIT", split)
         o, info = rl.rlgc_device(img, psf, max_iterations=6, rng_seed=11)
-        out[chain] = (o.clone(), info)
-    a, b = out["0"], out["1"]
-    assert tuple(a[1].padded_shape) == (32, 2187, 2187), a[1].padded_shape
-    assert (a[1].iterations, a[1].stop_reason) == (b[1].iterations, b[1].stop_reason)
-    np.testing.assert_allclose(a[1].kld_split1, b[1].kld_split1, rtol=1e-5, atol=1e-8)
-    err = float((a[0] - b[0]).abs().max() / a[0].abs().max())
-    assert err < 2e-5, err
+        out[update + split] = (o.clone(), info)
+    base = out["00"]
+    assert tuple(base[1].padded_shape) == (32, 2187, 2187), base[1].padded_shape
+    for key in ("10", "11", "01"):
+        a = out[key]
+        assert (a[1].iterations, a[1].stop_reason) == (base[1].iterations, base[1].stop_reason), key
+        np.testing.assert_allclose(a[1].kld_split1, base[1].kld_split1, rtol=1e-5, atol=1e-8, err_msg=key)
+        np.testing.assert_allclose(a[1].kld_image, base[1].kld_image, rtol=1e-5, atol=1e-8, err_msg=key)
+        err = float((a[0] - base[0]).abs().max() / base[0].abs().max())
+        assert err < 2e-5, (key, err)
+    # injected splits: two iterations' worth of a fixed half / half split
+    inj = torch.stack([torch.floor(img.float() / 2), torch.ceil(img.float() / 2)])
+    res = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("M3D_RLGC_CHAIN_SPLIT", split)
+        o, info = rl.rlgc_device(img, psf, max_iterations=2, rng_seed=11, injected_splits=inj)
+        res[split] = (o.clone(), info)
+    assert res["0"][1].iterations == res["1"][1].iterations
+    np.testing.assert_allclose(res["1"][1].kld_split2, res["0"][1].kld_split2, rtol=1e-5, atol=1e-8)
+    assert float((res["1"][0] - res["0"][0]).abs().max() / res["0"][0].abs().max()) < 2e-5
     rl.clear_rlgc_caches(clear_memory_pool=True)
 
 
