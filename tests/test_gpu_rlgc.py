@@ -289,6 +289,20 @@ def test_chained_passes_change_nothing(monkeypatch):
         np.testing.assert_allclose(a[1].kld_image, base[1].kld_image, rtol=1e-5, atol=1e-8, err_msg=key)
         err = float((a[0] - base[0]).abs().max() / base[0].abs().max())
         assert err < 2e-5, (key, err)
+    # a float32 image takes the kernel's other instantiation (chunked draw above 65535 counts): same volume as the
+    # uint16 image where the counts agree, and a count beyond uint16 goes through fused and unfused alike
+    imgf = img.float()
+    monkeypatch.setenv("M3D_RLGC_CHAIN_SPLIT", "1")
+    of, _ = rl.rlgc_device(imgf, psf, max_iterations=6, rng_seed=11)
+    assert torch.equal(of, out["11"][0])
+    imgf[5, 700:720, 900:930] = 150000.0
+    big = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("M3D_RLGC_CHAIN_SPLIT", split)
+        o, info = rl.rlgc_device(imgf, psf, max_iterations=3, rng_seed=11)
+        big[split] = (o.clone(), info)
+    assert big["0"][1].iterations == big["1"][1].iterations
+    assert float((big["1"][0] - big["0"][0]).abs().max() / big["0"][0].abs().max()) < 2e-5
     # injected splits: two iterations' worth of a fixed half / half split
     inj = torch.stack([torch.floor(img.float() / 2), torch.ceil(img.float() / 2)])
     res = {}
