@@ -364,7 +364,7 @@ def launch_ranks(n: int, argv: list[str]) -> int:
     pass its output and exit code on.  The parent has made no GPU call (GPUs are counted from the environment /
     sysfs) and never execs."""
     have = visible_gpu_count()
-    if have < n:
+    if have < n and os.environ.get("M3D_BENCH_BACKEND", "nccl") == "nccl":   # the gloo rehearsal shares one GPU
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
     env = dict(os.environ)
     env["M3D_BENCH_T0"] = repr(_T_IMPORT0)
