@@ -164,6 +164,12 @@ int m3d_binom_tables_host(const uint64_t **thresholds, int64_t *n_thresholds, co
 int m3d_binom_debug_table_draw(const uint32_t *q, const uint32_t *hi, const uint32_t *lo, int64_t n, uint32_t *out,
                                void *stream);
 
+/* Parity hook for the packed complex arithmetic the FFT passes are built from (csrc/m3d_fft.h: products with +-i,
+   complex products, Hermitian split / merge terms, 3- / 4- / 8- / 9-point butterflies): a, b, c are n complex64
+   values each, out receives 58 complex64 values per element (layout: k_debug_pk in csrc/m3d_fftconv.hip).  The
+   butterflies stand in for numpy.fft / scipy.fft inside rlgc.py:424-436's fft convolutions. */
+int m3d_fft_debug_pk(const float *a, const float *b, const float *c, int64_t n, float *out, void *stream);
+
 /* clip(0, 65535).astype(uint16) of RLGC output, DataRegistration.py:435, 993-995 */
 int m3d_clip_to_u16(const float *in, uint16_t *out, int64_t n, void *stream);
 

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "m3d_rlgc_debug_split": (c_int, [c_void_p, c_int, c_int64, c_uint64, c_int32, c_void_p, c_void_p]),
     "m3d_binom_tables_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "m3d_binom_debug_table_draw": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "m3d_fft_debug_pk": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "m3d_clip_to_u16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "m3d_weight_readout": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "m3d_gaussian_lowpass": (c_int, [c_void_p, c_void_p, c_void_p, _I3, _F3, c_int, c_void_p]),

@@ -47,22 +47,100 @@ struct AxisPlan {
     const int *pos;         // device: position of frequency k after the DIF pass
 };
 
-// Complex arithmetic on the two-lane vector type: the passes are instruction-issue bound (one wave instruction per
-// four cycles per SIMD, whatever its kind), and v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 handle real and imaginary
-// part in one issue.  Written on HIP's float2 operators (native ext_vector arithmetic) so that the compiler selects
-// the packed forms with their op_sel / neg modifiers instead of relying on the SLP vectoriser.
+// Complex arithmetic on the two-lane vector type: the passes are vector-ALU bound (one wave instruction per four
+// cycles per SIMD, whatever its kind), and v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 handle real and imaginary part
+// in one issue.  Sums, differences and products with real pairs are written on HIP's float2 operators (the compiler
+// selects the packed forms).  What it does NOT select is a swap of the halves combined with a sign on ONE of them -
+// every multiplication by +-i and every complex product is that - although the instruction encodes both for free
+// (op_sel / op_sel_hi choose the half of each source per result lane, neg_lo / neg_hi negate a source per lane): it
+// emits v_xor + v_mov in front of the packed operation instead (27 % of the dual X pass's vector instructions in
+// round 2).  Those forms are spelled out below as one instruction each.
+//   result.lo = [-]src0[op_sel[0]] * src1[op_sel[1]] + src2[op_sel[2]]          (neg_lo)
+//   result.hi = [-]src0[op_sel_hi[0]] * src1[op_sel_hi[1]] + src2[op_sel_hi[2]]  (neg_hi)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f nv(float2 a)
+{
+    v2f r = {a.x, a.y};
+    return r;
+}
+__device__ __forceinline__ float2 f2(v2f a) { return make_float2(a.x, a.y); }
 __device__ __forceinline__ float2 swap_xy(float2 a) { return make_float2(a.y, a.x); }
 __device__ __forceinline__ float2 xx(float2 a) { return make_float2(a.x, a.x); }
 __device__ __forceinline__ float2 yy(float2 a) { return make_float2(a.y, a.y); }
+// b + i x = (b.x - x.y, b.y + x.x)
+__device__ __forceinline__ float2 add_i(float2 b, float2 x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(nv(b)), "v"(nv(x)));
+    return f2(r);
+}
+// b - i x = (b.x + x.y, b.y - x.x)
+__device__ __forceinline__ float2 sub_i(float2 b, float2 x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(nv(b)), "v"(nv(x)));
+    return f2(r);
+}
+// conj(a) + i conj(b) = (a.x + b.y, b.x - a.y): the mirror element of the Hermitian merge
+__device__ __forceinline__ float2 conj_add_i_conj(float2 a, float2 b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(nv(a)), "v"(nv(b)));
+    return f2(r);
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y) and -i (a - conj(b)) = (a.y + b.y, b.x - a.x): the two halves of the Hermitian
+// split (before the factor 1/2)
+__device__ __forceinline__ float2 add_conj(float2 a, float2 b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(nv(a)), "v"(nv(b)));
+    return f2(r);
+}
+__device__ __forceinline__ float2 split_odd(float2 a, float2 b)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(nv(a)), "v"(nv(b)));
+    return f2(r);
+}
+// m + i s x and m - i s x for a real s held in a scalar register pair (butterfly constants).  Both result lanes
+// read the LOW register of the pair (op_sel_hi 0): a packed-f32 instruction cannot take the high half of a scalar
+// source for its high lane - the compiler's own packed code never does either (tests/test_gpu_fft_primitives.py
+// pins the form used here).
+__device__ __forceinline__ float2 fma_i(float2 x, float2 s, float2 m)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]"
+        : "=v"(r)
+        : "v"(nv(x)), "s"(nv(s)), "v"(nv(m)));
+    return f2(r);
+}
+__device__ __forceinline__ float2 fms_i(float2 x, float2 s, float2 m)
+{
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]"
+        : "=v"(r)
+        : "v"(nv(x)), "s"(nv(s)), "v"(nv(m)));
+    return f2(r);
+}
+// a b = (a.x b.x - a.y b.y, a.y b.x + a.x b.y): (a.x, a.y) b.x, then (-a.y, a.x) b.y added
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
-    // (a.x b.x - a.y b.y, a.x b.y + a.y b.x) = a.xx * b + a.yy * (-b.y, b.x)
-    return xx(a) * b + yy(a) * make_float2(-b.y, b.x);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(nv(a)), "v"(nv(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+        : "=v"(r)
+        : "v"(nv(a)), "v"(nv(b)), "v"(t));
+    return f2(r);
 }
-__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)  // a * conj(b)
+// a conj(b) = (a.x b.x + a.y b.y, a.y b.x - a.x b.y)
+__device__ __forceinline__ float2 cmul_conj(float2 a, float2 b)
 {
-    // (a.x b.x + a.y b.y, a.y b.x - a.x b.y) = xx(b) * a + yy(b) * (a.y, -a.x)
-    return xx(b) * a + yy(b) * make_float2(a.y, -a.x);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(nv(a)), "v"(nv(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r)
+        : "v"(nv(a)), "v"(nv(b)), "v"(t));
+    return f2(r);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return a + b; }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return a - b; }
@@ -72,12 +150,23 @@ __device__ __forceinline__ float2 rot90(float2 a)
 {
     return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
 }
-// multiply by the constant exp(-+ i theta) given (cos, sin)
+// b + W4 x and b - W4 x with W4 = -i (forward) / +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 add_rot90(float2 b, float2 x)
+{
+    return INV ? add_i(b, x) : sub_i(b, x);
+}
+template <bool INV>
+__device__ __forceinline__ float2 sub_rot90(float2 b, float2 x)
+{
+    return INV ? sub_i(b, x) : add_i(b, x);
+}
+// multiply by the constant exp(-+ i theta) given (cos, sin): a c -+ i s a
 template <bool INV>
 __device__ __forceinline__ float2 ctw(float2 a, float c, float s)
 {
-    // forward: (a.x c + a.y s, a.y c - a.x s) = a c + (a.y, -a.x) s ; inverse: a c + (-a.y, a.x) s
-    return a * make_float2(c, c) + rot90<INV>(a) * make_float2(s, s);
+    const float2 t = a * make_float2(c, c);
+    return INV ? fma_i(a, make_float2(s, s), t) : fms_i(a, make_float2(s, s), t);
 }
 
 template <bool INV>
@@ -90,24 +179,23 @@ __device__ __forceinline__ void dft2(float2 &a, float2 &b)
 template <bool INV>
 __device__ __forceinline__ void dft3(float2 &v0, float2 &v1, float2 &v2)
 {
-    const float s = 0.86602540378443864676f;
+    const float2 s = make_float2(0.86602540378443864676f, 0.86602540378443864676f);
     const float2 t1 = v1 + v2;
+    const float2 d = v1 - v2;
     const float2 t2 = v0 - t1 * make_float2(0.5f, 0.5f);
-    const float2 d = (v1 - v2) * make_float2(s, s);
-    const float2 t3 = rot90<INV>(d);
     v0 = v0 + t1;
-    v1 = t2 + t3;
-    v2 = t2 - t3;
+    v1 = INV ? fma_i(d, s, t2) : fms_i(d, s, t2);
+    v2 = INV ? fms_i(d, s, t2) : fma_i(d, s, t2);
 }
 template <bool INV>
 __device__ __forceinline__ void dft4(float2 &v0, float2 &v1, float2 &v2, float2 &v3)
 {
     const float2 a = cadd(v0, v2), b = csub(v0, v2);
-    const float2 c = cadd(v1, v3), d = rot90<INV>(csub(v1, v3));
+    const float2 c = cadd(v1, v3), e = csub(v1, v3);
     v0 = cadd(a, c);
     v2 = csub(a, c);
-    v1 = cadd(b, d);
-    v3 = csub(b, d);
+    v1 = add_rot90<INV>(b, e);
+    v3 = sub_rot90<INV>(b, e);
 }
 template <bool INV>
 __device__ __forceinline__ void dft8(float2 *v)
@@ -117,12 +205,16 @@ __device__ __forceinline__ void dft8(float2 *v)
     dft4<INV>(v[0], v[2], v[4], v[6]);
     dft4<INV>(v[1], v[3], v[5], v[7]);
     v[3] = ctw<INV>(v[3], h, h);
-    v[5] = rot90<INV>(v[5]);
     v[7] = ctw<INV>(v[7], -h, h);
     float2 o[8];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float2 a = v[2 * c], b = v[2 * c + 1];
+        if (c == 2) {  // v[5] carries W8^2 = -+i
+            o[c] = add_rot90<INV>(a, b);
+            o[c + 4] = sub_rot90<INV>(a, b);
+            continue;
+        }
         dft2<INV>(a, b);
         o[c] = a;
         o[c + 4] = b;

@@ -600,18 +600,25 @@ __device__ __forceinline__ void forward_pair_emit(const float2 (&c1)[9], const f
     const int k2p = kp == 0 ? 0 : S - kp;
     int rows_c = 0;
     const int rbase = STAGED ? 0 : row_base(g, min(ya, g.Yp - 1), rows_c);
+    const float2 half = make_float2(0.5f, 0.5f);
     auto put = [&](int k, float2 c, float2 m) {
+        // A = (c + conj(m)) / 2, B = -i (c - conj(m)) / 2
+        const float2 A = add_conj(c, m) * half, B = split_odd(c, m) * half;
         if constexpr (STAGED) {
-            stage[stage_slot(k, r0)] = make_float2(0.5f * (c.x + m.x), 0.5f * (c.y - m.y));
-            stage[stage_slot(k, r0 + 1)] = make_float2(0.5f * (c.y + m.y), 0.5f * (m.x - c.x));
+            stage[stage_slot(k, r0)] = A;
+            stage[stage_slot(k, r0 + 1)] = B;
         } else {
             const int in_plane = rbase + tile_term(g, k, rows_c);  // row ya + 1 (same chunk: ya is even) follows at + TW
-            if (wa) spec[zterm + in_plane] = make_float2(0.5f * (c.x + m.x), 0.5f * (c.y - m.y));
-            if (wb) spec[zterm + in_plane + g.TW] = make_float2(0.5f * (c.y + m.y), 0.5f * (m.x - c.x));
+            if (wa) spec[zterm + in_plane] = A;
+            if (wb) spec[zterm + in_plane + g.TW] = B;
         }
     };
 #pragma unroll
-    for (int d = 0; d < 5; ++d) put(kp + S * d, c1[d], kp == 0 ? c1[(9 - d) % 9] : c2[8 - d]);
+    for (int d = 0; d < 5; ++d) {  // selected by value: a conditional on the array elements themselves becomes a
+                                   // pointer select and sends both arrays to scratch
+        const float2 m0 = c1[(9 - d) % 9], m1 = c2[8 - d];
+        put(kp + S * d, c1[d], make_float2(kp == 0 ? m0.x : m1.x, kp == 0 ? m0.y : m1.y));
+    }
     if (k2p != kp) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) put(k2p + S * d, c2[d], c1[8 - d]);
@@ -651,8 +658,8 @@ __device__ __forceinline__ void inverse_pair_merge(float2 *row, int S, int N, in
     for (int d = 0; d < 5; ++d) {
         const float2 A = Av[d], B = Bv[d];
         const int k = kp + S * d;
-        c1[d] = make_float2(A.x - B.y, A.y + B.x);
-        const float2 mir = make_float2(A.x + B.y, B.x - A.y);
+        c1[d] = add_i(A, B);
+        const float2 mir = conj_add_i_conj(A, B);
         if (kp == 0) {
             if (d != 0) c1[9 - d] = mir;
         } else if (2 * k != N) {
@@ -663,8 +670,8 @@ __device__ __forceinline__ void inverse_pair_merge(float2 *row, int S, int N, in
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const float2 A = Av[5 + d], B = Bv[5 + d];
-            c2[d] = make_float2(A.x - B.y, A.y + B.x);
-            c1[8 - d] = make_float2(A.x + B.y, B.x - A.y);
+            c2[d] = add_i(A, B);
+            c1[8 - d] = conj_add_i_conj(A, B);
         }
         dft9<true>(c2);
 #pragma unroll
@@ -2405,5 +2412,60 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
     return M3D_OK;
 }
 
-}  // namespace m3d
+// ---------------------------------------------------------------- parity hook for the packed complex primitives
+// out[i][slot]: the primitives of m3d_fft.h applied to (a[i], b[i], c[i]); slots 10.. hold the 3-, 4-, 8- and
+// 9-point butterflies (forward, then inverse) of the sequence a, b, c, a + b, b - c, c * a (element by element), a - c,
+// b + b, c - a.
+namespace {
+__global__ void k_debug_pk(const float2 *__restrict__ a, const float2 *__restrict__ b, const float2 *__restrict__ c,
+                           int64_t n, float2 *__restrict__ out)
+{
+    using namespace m3d;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 A = a[i], B = b[i], C = c[i];
+    float2 *o = out + i * kDebugPkSlots;
+    const float2 s = make_float2(C.x, C.x);
+    o[0] = add_i(A, B);
+    o[1] = sub_i(A, B);
+    o[2] = conj_add_i_conj(A, B);
+    o[3] = add_conj(A, B);
+    o[4] = split_odd(A, B);
+    o[5] = make_float2(0.f, 0.f);
+    o[6] = make_float2(0.f, 0.f);
+    o[7] = cmul(A, B);
+    o[8] = cmul_conj(A, B);
+    o[9] = ctw<false>(A, 0.6f, 0.8f);
+    // scalar-register pairs: the value must be wave uniform - taken from element 0
+    const float su = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s.x)));
+    const float2 s0 = make_float2(su, su);
+    o[5] = fma_i(A, s0, B);
+    o[6] = fms_i(A, s0, B);
+    const float2 seq[9] = {A, B, C, A + B, B - C, C * A, A - C, B + B, C - A};
+    int at = 10;
+    auto run = [&](auto fn, int R) {
+        float2 v[9];
+        for (int q = 0; q < 9; ++q) v[q] = seq[q];
+        fn(v);
+        for (int q = 0; q < R; ++q) o[at++] = v[q];
+    };
+    run([](float2 *v) { dft3<false>(v[0], v[1], v[2]); }, 3);
+    run([](float2 *v) { dft3<true>(v[0], v[1], v[2]); }, 3);
+    run([](float2 *v) { dft4<false>(v[0], v[1], v[2], v[3]); }, 4);
+    run([](float2 *v) { dft4<true>(v[0], v[1], v[2], v[3]); }, 4);
+    run([](float2 *v) { dft8<false>(v); }, 8);
+    run([](float2 *v) { dft8<true>(v); }, 8);
+    run([](float2 *v) { dft9<false>(v); }, 9);
+    run([](float2 *v) { dft9<true>(v); }, 9);
+}
+}  // namespace
 
+int fft_debug_pk(const float2 *a, const float2 *b, const float2 *c, int64_t n, float2 *out, void *stream)
+{
+    if (n <= 0) return M3D_OK;
+    hipLaunchKernelGGL(k_debug_pk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, c, n, out);
+    M3D_KERNEL_CHECK();
+    return M3D_OK;
+}
+
+}  // namespace m3d

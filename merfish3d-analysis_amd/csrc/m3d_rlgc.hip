@@ -1221,6 +1221,12 @@ int m3d_rlgc_debug_split(const void *image, int image_dtype, int64_t n, uint64_t
     return M3D_OK;
 }
 
+int m3d_fft_debug_pk(const float *a, const float *b, const float *c, int64_t n, float *out, void *stream_v)
+{
+    M3D_REQUIRE(a && b && c && out && n >= 0, "null pointer");
+    return m3d::fft_debug_pk((const float2 *)a, (const float2 *)b, (const float2 *)c, n, (float2 *)out, stream_v);
+}
+
 int m3d_binom_debug_table_draw(const uint32_t *q, const uint32_t *hi, const uint32_t *lo, int64_t n, uint32_t *out,
                                void *stream_v)
 {
