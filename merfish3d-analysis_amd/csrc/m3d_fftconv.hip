@@ -45,6 +45,12 @@ using namespace m3d;
 #endif
 #define M3D_KU_Z 8
 #endif
+#ifndef M3D_DUAL_UN_EARLY
+#define M3D_DUAL_UN_EARLY 0
+#endif
+#ifndef M3D_UPD_LOADS_EARLY
+#define M3D_UPD_LOADS_EARLY 1
+#endif
 #ifndef M3D_KU_Y
 #define M3D_KU_Y 3
 #endif
@@ -506,6 +512,132 @@ __device__ __forceinline__ void edge_twiddles(float2 (&w)[9], const float2 *__re
     w[8] = cmul(w[4], w[4]);
 }
 
+// The static X kernels (N = 2187 = 9 * 9 * 3 * 9 at 256 threads) request every twiddle they will need when they start,
+// next to their first data loads: a table load in front of a stage is a trip to L2 (the streams evict the table from
+// L1) that the whole stage waits for - four such trips per middle pass and one per edge stage in round 2's kernels,
+// at four waves per SIMD.  A thread's butterfly indices are the same in every stage of one kind, so nine values serve
+// the whole kernel: edge stages W^(t q), q = 1, 2, 4 (t = tid), block-243 stage W^(9 j q) with j = tid % 27, block-27
+// stage W^(81 j) with j = (tid + 256 k) % 9, k < 3.  The other powers are the same products as before.
+struct XTwiddles {
+    float2 e1, e2, e4;  // edge stages
+    float2 a1, a2, a4;  // block-243 stage (radix 9)
+    float2 b[3];        // block-27 stage (radix 3), items tid + 256 k
+};
+__device__ __forceinline__ XTwiddles x_twiddles_2187(const float2 *__restrict__ tw, int tid)
+{
+    XTwiddles x;
+    const int t = min(tid, 242), j1 = (tid % 27) * 9;
+    x.e1 = tw[t];
+    x.e2 = tw[2 * t];
+    x.e4 = tw[4 * t];
+    x.a1 = tw[j1];
+    x.a2 = tw[2 * j1];
+    x.a4 = tw[4 * j1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x.b[k] = tw[81 * ((tid + 256 * k) % 9)];
+    return x;
+}
+__device__ __forceinline__ void powers_124(float2 (&w)[9], float2 w1, float2 w2, float2 w4)
+{
+    w[1] = w1;
+    w[2] = w2;
+    w[4] = w4;
+    w[3] = cmul(w[1], w[2]);
+    w[5] = cmul(w[1], w[4]);
+    w[6] = cmul(w[2], w[4]);
+    w[7] = cmul(w[3], w[4]);
+    w[8] = cmul(w[4], w[4]);
+}
+// Middle stages of NB rows (row r at lds + r * 2187) with the twiddles in registers; every row's elements are read
+// before the first butterfly (NB * 9 independent LDS reads in flight instead of 9, and nothing between them and the
+// butterflies but arithmetic).  Same operations in the same order as lds_stage<9> / lds_stage<3>.
+template <bool INV, int NB>
+__device__ __forceinline__ void x_stage243(float2 *lds, int tid, const XTwiddles &x)
+{
+    if (tid >= 243) return;
+    float2 w[9];
+    powers_124(w, x.a1, x.a2, x.a4);
+    const int blk = tid / 27, j = tid - blk * 27;
+    float2 *p = lds + blk * 243 + j;
+    float2 v[NB][9];
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) v[r][q] = p[r * 2187 + q * 27];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        if (INV) {
+#pragma unroll
+            for (int q = 1; q < 9; ++q) v[r][q] = cmul_conj(v[r][q], w[q]);
+            dft9<true>(v[r]);
+        } else {
+            dft9<false>(v[r]);
+#pragma unroll
+            for (int q = 1; q < 9; ++q) v[r][q] = cmul(v[r][q], w[q]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p[r * 2187 + q * 27] = v[r][q];
+}
+template <bool INV, int NB>
+__device__ __forceinline__ void x_stage27(float2 *lds, int tid, const XTwiddles &x)
+{
+    float2 v[3][NB][3];
+    int at[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int t = min(tid + 256 * k, 728), blk = t / 9, j = t - blk * 9;
+        at[k] = blk * 27 + j;
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[k][r][q] = lds[at[k] + r * 2187 + q * 9];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float2 w1 = x.b[k], w2 = cmul(w1, w1);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            float2(&u)[3] = v[k][r];
+            if (INV) {
+                u[1] = cmul_conj(u[1], w1);
+                u[2] = cmul_conj(u[2], w2);
+                dft3<true>(u[0], u[1], u[2]);
+            } else {
+                dft3<false>(u[0], u[1], u[2]);
+                u[1] = cmul(u[1], w1);
+                u[2] = cmul(u[2], w2);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (tid + 256 * k >= 729) continue;  // (the clamped item above only read)
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) lds[at[k] + r * 2187 + q * 9] = v[k][r][q];
+    }
+}
+template <int NB>
+__device__ __forceinline__ void middle_forward_2187(float2 *lds, int tid, const XTwiddles &x)
+{
+    x_stage243<false, NB>(lds, tid, x);
+    __syncthreads();
+    x_stage27<false, NB>(lds, tid, x);
+    __syncthreads();
+}
+template <int NB>
+__device__ __forceinline__ void middle_inverse_2187(float2 *lds, int tid, const XTwiddles &x)
+{
+    x_stage27<true, NB>(lds, tid, x);
+    __syncthreads();
+    x_stage243<true, NB>(lds, tid, x);
+    __syncthreads();
+}
+
 // Static geometry (see k_y_pass_static): NS = 2187 fixes Xp = Yp = 2187, TW = 4, four rows per X block, 128-row
 // chunks and the radix list 9 * 9 * 3 * 9, so the index arithmetic of a pass folds into immediates.  NS = 0: run time.
 template <int NS>
@@ -714,9 +846,12 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
         pu1 = ax.pos[kp];
         pu2 = ax.pos[kp == 0 ? 0 : S - kp];
     }
+    XTwiddles xt;
+    if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
     if (tid < S) {
         float2 w[9];
-        edge_twiddles(w, ax.tw, tid);
+        if constexpr (NS == 2187) powers_124(w, xt.e1, xt.e2, xt.e4);
+        else edge_twiddles(w, ax.tw, tid);
         const int zs = g.mirror == 1 ? sym_src(z, g.mir.z0, g.mir.nz) : z;
         for (int bi = 0; bi < nb; ++bi) {
             const int ya = y0 + 2 * bi, yb = ya + 1;
@@ -749,7 +884,8 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
         }
     }
     __syncthreads();
-    middle_forward<RSET, NS>(lds_fr, ax, nb, N, tid, nt, g.GX);
+    if constexpr (NS == 2187) middle_forward_2187<2>(lds_fr, tid, xt);
+    else middle_forward<RSET, NS>(lds_fr, ax, nb, N, tid, nt, g.GX);
     {
         float2 c1[9], c2[9];
         if (pair_live) forward_pair_load(lds_fr + pbi * N, pu1 / 9, pu2 / 9, c1, c2);
@@ -802,6 +938,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
     const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     int u1 = 0, u2 = 0;
+    XTwiddles xt;
+    if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
     if (tid < nb * I) {
         u1 = ax.pos[kp];
         u2 = ax.pos[kp == 0 ? 0 : S - kp];
@@ -833,12 +971,15 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
         inverse_pair_merge(lds_ir + pbi * N, S, N, kp, u1 / 9, u2 / 9, Av, Bv);
     }
     __syncthreads();
-    middle_inverse<RSET, NS>(lds_ir, ax, nb, N, tid, nt, g.GX);
+    if constexpr (NS == 2187) middle_inverse_2187<2>(lds_ir, tid, xt);
+    else middle_inverse<RSET, NS>(lds_ir, ax, nb, N, tid, nt, g.GX);
     float mx = -INFINITY, dmax = 0.0f;
     unsigned int updated = 0;
     if (tid < S) {
         float2 w[9];
-        edge_twiddles(w, ax.tw, tid);
+        // (the chained update pass is at its register limit: its edge twiddles come from the table where they are used)
+        if constexpr (NS == 2187 && !CHAIN) powers_124(w, xt.e1, xt.e2, xt.e4);
+        else edge_twiddles(w, ax.tw, tid);
         for (int bi = 0; bi < nb; ++bi) {
             const int yr[2] = {y0 + 2 * bi, y0 + 2 * bi + 1};
             bool valid[2];
@@ -847,6 +988,19 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
             for (int r = 0; r < 2; ++r) {
                 valid[r] = yr[r] >= g.out.y0 && yr[r] < y_hi;
                 rowo[r] = ((int64_t)z * g.Yp + (valid[r] ? yr[r] : g.out.y0)) * N;
+            }
+            // M3D_UPD_LOADS_EARLY: the tail's operands of both rows (36 registers) are requested in front of the last
+            // stage instead of one row at a time behind it (the kernel sat at its register limit in round 2)
+            float ava[2][9], bva[2][9];
+            if constexpr (EPI != m3d::ConvEpilogue::kNone && M3D_UPD_LOADS_EARLY) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {
+                        const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
+                        ava[r][q] = ep.a[rowo[r] + n];
+                        bva[r][q] = ep.b[rowo[r] + n];
+                    }
             }
             float2 v[9];
             const float2 *row = lds_ir + bi * N + tid;
@@ -860,15 +1014,20 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
             // one output row after the other (tail operands of one row = 18 registers), after the butterflies
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!M3D_UPD_LOADS_EARLY) __builtin_amdgcn_sched_barrier(0);
                 if (!valid[r]) continue;
                 float av[9], bv[9];
                 if constexpr (EPI != m3d::ConvEpilogue::kNone) {
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
-                        const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
-                        av[q] = ep.a[rowo[r] + n];
-                        bv[q] = ep.b[rowo[r] + n];
+                        if constexpr (M3D_UPD_LOADS_EARLY) {
+                            av[q] = ava[r][q];
+                            bv[q] = bva[r][q];
+                        } else {
+                            const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
+                            av[q] = ep.a[rowo[r] + n];
+                            bv[q] = ep.b[rowo[r] + n];
+                        }
                     }
                 }
 #pragma unroll
@@ -924,7 +1083,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
             }
         }
         __syncthreads();
-        middle_forward<RSET, NS>(lds_ir, ax, nb, N, tid, nt, g.GX);
+        middle_forward_2187<2>(lds_ir, tid, xt);
         {
             float2 c1[9], c2[9];
             const bool pair_live = tid < nb * I;
@@ -990,6 +1149,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     const bool pair_live = tid < 2 * I;
     int pu1 = 0, pu2 = 0;
+    XTwiddles xt;
+    if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
     if (pair_live) {
         pu1 = ax.pos[kp] / 9;
         pu2 = ax.pos[kp == 0 ? 0 : S - kp] / 9;
@@ -1005,13 +1166,13 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         }
         inverse_pair_merge(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
     }
-    __syncthreads();
-    middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
-    // 1 / update_norm of both rows.  Requested here, not in front of the middle stages: 18 registers held across
-    // them cost more (spills, 3.23 -> 3.04 ms) than the exposed latency of these coalesced loads
+    // 1 / update_norm of both rows.  M3D_DUAL_UN_EARLY: requested in front of the middle stages (18 registers held
+    // across them - spills at the 128 registers the kernel needed in round 2, 3.23 -> 3.04 ms for requesting them
+    // late; the packed-instruction forms freed 24)
     const bool row1 = y0 + 1 < g.Yp;
     const int64_t r0 = ((int64_t)z * g.Yp + y0) * N, r1 = r0 + (row1 ? N : 0);
     float un0[9], un1[9];
+#if M3D_DUAL_UN_EARLY
     if (tid < S) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -1019,10 +1180,24 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             un1[q] = ep.b[r1 + tid + S * q];
         }
     }
+#endif
+    __syncthreads();
+    if constexpr (NS == 2187) middle_inverse_2187<2>(lds_dr, tid, xt);
+    else middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
+#if !M3D_DUAL_UN_EARLY
+    if (tid < S) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            un0[q] = ep.b[r0 + tid + S * q];
+            un1[q] = ep.b[r1 + tid + S * q];
+        }
+    }
+#endif
     float mn = INFINITY, mx = -INFINITY;
     if (tid < S) {
         float2 w[9];
-        edge_twiddles(w, ax.tw, tid);
+        if constexpr (NS == 2187) powers_124(w, xt.e1, xt.e2, xt.e4);
+        else edge_twiddles(w, ax.tw, tid);
         const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
         float2 pk[9];
         // one row after the other: both rows' butterflies in flight at once cost 40 registers more than there are
@@ -1084,7 +1259,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         }
     }
     if constexpr (CHAIN) {
-        middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
+        if constexpr (NS == 2187) middle_forward_2187<1>(lds_dr, tid, xt);
+        else middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
         if (tid < I) {
             float2 c1[9], c2[9];
             forward_pair_load(lds_dr, pu1, pu2, c1, c2);
@@ -1154,6 +1330,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
         inverse_pair_merge(lds_sp, S, N, kp, pu1, pu2, Av, Bv);
     }
     __syncthreads();
+    // (table twiddles: this kernel is bound by its vector arithmetic - Philox, the threshold search, the split - and
+    // holds 128 registers; the register twiddles of the other static X kernels cost it 6 %)
     middle_inverse<1, 2187>(lds_sp, ax, 1, N, tid, 256, g.GX);
     const float eps = 1e-4f;
     float sums[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // A, Bim, B1, B2, Tim, T1, T2 of this thread's 18 voxels
@@ -1175,7 +1353,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
             }
         }
         float2 w[9];
-        edge_twiddles(w, ax.tw, tid);
+        edge_twiddles(w, ax.tw, tid);  // (register limit: from the table, behind the image loads)
         float2 v[9];  // (Hu of row ya, Hu of row ya + 1) at x = tid + S q
         const float2 *row = lds_sp + tid;
         v[0] = row[0];
