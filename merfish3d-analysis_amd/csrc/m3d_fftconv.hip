@@ -45,12 +45,6 @@ using namespace m3d;
 #endif
 #define M3D_KU_Z 8
 #endif
-#ifndef M3D_DUAL_UN_EARLY
-#define M3D_DUAL_UN_EARLY 0
-#endif
-#ifndef M3D_UPD_LOADS_EARLY
-#define M3D_UPD_LOADS_EARLY 1
-#endif
 #ifndef M3D_KU_Y
 #define M3D_KU_Y 3
 #endif
@@ -989,10 +983,10 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
                 valid[r] = yr[r] >= g.out.y0 && yr[r] < y_hi;
                 rowo[r] = ((int64_t)z * g.Yp + (valid[r] ? yr[r] : g.out.y0)) * N;
             }
-            // M3D_UPD_LOADS_EARLY: the tail's operands of both rows (36 registers) are requested in front of the last
-            // stage instead of one row at a time behind it (the kernel sat at its register limit in round 2)
+            // the tail's operands of both rows (36 registers) are requested in front of the last stage, not one row at a
+            // time behind it as in round 2, when the kernel sat at its register limit (1.27 -> 1.22 ms)
             float ava[2][9], bva[2][9];
-            if constexpr (EPI != m3d::ConvEpilogue::kNone && M3D_UPD_LOADS_EARLY) {
+            if constexpr (EPI != m3d::ConvEpilogue::kNone) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1011,23 +1005,15 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
             float2 pk[9];  // CHAIN: (new row 2 bi, new row 2 bi + 1) at x = tid + S q; zero outside the core
 #pragma unroll
             for (int q = 0; q < 9; ++q) pk[q] = make_float2(0.f, 0.f);
-            // one output row after the other (tail operands of one row = 18 registers), after the butterflies
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                if constexpr (!M3D_UPD_LOADS_EARLY) __builtin_amdgcn_sched_barrier(0);
                 if (!valid[r]) continue;
                 float av[9], bv[9];
                 if constexpr (EPI != m3d::ConvEpilogue::kNone) {
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
-                        if constexpr (M3D_UPD_LOADS_EARLY) {
-                            av[q] = ava[r][q];
-                            bv[q] = bva[r][q];
-                        } else {
-                            const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
-                            av[q] = ep.a[rowo[r] + n];
-                            bv[q] = ep.b[rowo[r] + n];
-                        }
+                        av[q] = ava[r][q];
+                        bv[q] = bva[r][q];
                     }
                 }
 #pragma unroll
@@ -1166,25 +1152,15 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         }
         inverse_pair_merge(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
     }
-    // 1 / update_norm of both rows.  M3D_DUAL_UN_EARLY: requested in front of the middle stages (18 registers held
-    // across them - spills at the 128 registers the kernel needed in round 2, 3.23 -> 3.04 ms for requesting them
-    // late; the packed-instruction forms freed 24)
-    const bool row1 = y0 + 1 < g.Yp;
-    const int64_t r0 = ((int64_t)z * g.Yp + y0) * N, r1 = r0 + (row1 ? N : 0);
-    float un0[9], un1[9];
-#if M3D_DUAL_UN_EARLY
-    if (tid < S) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            un0[q] = ep.b[r0 + tid + S * q];
-            un1[q] = ep.b[r1 + tid + S * q];
-        }
-    }
-#endif
     __syncthreads();
     if constexpr (NS == 2187) middle_inverse_2187<2>(lds_dr, tid, xt);
     else middle_inverse<RSET, NS>(lds_dr, ax, 2, N, tid, nt, g.GX);
-#if !M3D_DUAL_UN_EARLY
+    // 1 / update_norm of both rows.  Requested here, not in front of the middle stages: 18 registers held across them
+    // cost more than the exposed latency of these coalesced loads (round 2: spills, 3.23 -> 3.04 ms; round 3, with 24
+    // registers to spare: 2.90 vs 2.81 ms)
+    const bool row1 = y0 + 1 < g.Yp;
+    const int64_t r0 = ((int64_t)z * g.Yp + y0) * N, r1 = r0 + (row1 ? N : 0);
+    float un0[9], un1[9];
     if (tid < S) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
@@ -1192,7 +1168,6 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             un1[q] = ep.b[r1 + tid + S * q];
         }
     }
-#endif
     float mn = INFINITY, mx = -INFINITY;
     if (tid < S) {
         float2 w[9];
@@ -1512,6 +1487,9 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
     // forward passes need 80-88 registers for it (twiddles applied after the butterfly keep both columns live), which
     // costs the second 1024-thread block per CU (spills at 64: 2.7 ms) or, with 768-thread blocks, gives back what the
     // saved instructions bring (647 vs 655 us; the mirror pass 570 vs 483 us) - they stay at one column per item.
+    // Requesting the three radix-9 stages' twiddles at kernel start, in front of the tile's loads (18 registers), moved
+    // nothing either (643 vs 650 us forward, 500 vs 480 us mirror, inverse 705 vs 704 us with one column per item): the Y
+    // pass does not wait for its table loads.
     constexpr int CPT = (TWc % CPT_ == 0) ? CPT_ : 1, GR = TWc / CPT;
 #pragma unroll 1
     for (int t = tid; t < per_fft * GR; t += NT_) {
@@ -1519,7 +1497,9 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
         const int blk = it / sub, j = it - blk * sub;
         float2 w[R];
         const int j1 = j * twstep;
-        if constexpr (R == 9) {
+        constexpr bool kUnit = sub == 1;  // block size = radix: every twiddle is W^0 = 1, the products are skipped
+        if constexpr (kUnit) {
+        } else if constexpr (R == 9) {
             w[1] = tw[j1];
             w[2] = tw[2 * j1];
             w[4] = tw[4 * j1];
@@ -1551,13 +1531,17 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             if (INV) {
+                if constexpr (!kUnit) {
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[u][q] = cmul_conj(v[u][q], w[q]);
+                    for (int q = 1; q < R; ++q) v[u][q] = cmul_conj(v[u][q], w[q]);
+                }
                 dft_r<R, true>(v[u]);
             } else {
                 dft_r<R, false>(v[u]);
+                if constexpr (!kUnit) {
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[u][q] = cmul(v[u][q], w[q]);
+                    for (int q = 1; q < R; ++q) v[u][q] = cmul(v[u][q], w[q]);
+                }
             }
         }
         if constexpr (CPT == 2) {
