@@ -25,6 +25,16 @@ struct U32x4 {
 // r02_pmc_sq_rlgc_after.json: one vector instruction per four cycles per SIMD, 1.5 G of them per launch).
 constexpr int kSplitRounds = 7;
 
+// a ^ b ^ c: one v_bitop3_b32 on the device (the compiler emits two v_xor_b32 for the expression)
+M3D_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 template <int ROUNDS>
 M3D_HD U32x4 philox4x32(U32x4 c, uint32_t k0, uint32_t k1)
 {
@@ -35,9 +45,9 @@ M3D_HD U32x4 philox4x32(U32x4 c, uint32_t k0, uint32_t k1)
         const uint64_t p0 = (uint64_t)M0 * c.x;
         const uint64_t p1 = (uint64_t)M1 * c.z;
         U32x4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.x = xor3((uint32_t)(p1 >> 32), c.y, k0);
         n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.z = xor3((uint32_t)(p0 >> 32), c.w, k1);
         n.w = (uint32_t)p0;
         c = n;
         k0 += W0;
