@@ -102,7 +102,8 @@ __device__ __forceinline__ float2 split_odd(float2 a, float2 b)
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(nv(a)), "v"(nv(b)));
     return f2(r);
 }
-// m + i s x and m - i s x for a real s held in a scalar register pair (butterfly constants).  Both result lanes
+// m + i s x and m - i s x for a real s held in a scalar register pair: s must be uniform over the wave (the butterfly
+// constants are; a per-lane value would be read from its first lane only).  Both result lanes
 // read the LOW register of the pair (op_sel_hi 0): a packed-f32 instruction cannot take the high half of a scalar
 // source for its high lane - the compiler's own packed code never does either (tests/test_gpu_fft_primitives.py
 // pins the form used here).
