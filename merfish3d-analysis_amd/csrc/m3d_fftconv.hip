@@ -71,7 +71,6 @@ struct FftConvPlan {
     int xcdpair;
     int ystatic;  // the Y pass runs its static-geometry build
     int xstatic;  // the register-edge X passes run their static-geometry builds (NS = 2187)
-    int dual4;    // static chained dual pass with four rows per 512-thread workgroup
 };
 
 }  // namespace m3d
@@ -1245,126 +1244,6 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     }
 }
 
-// The chained dual pass with FOUR rows per workgroup (static geometry): two halves of 256 threads, each running the
-// two-row pass above on its own pair of LDS rows; the four rows are the four rows of the spectrum's 128-byte lines
-// (tile kt, rows y0 .. y0 + 3), so both halves read the same lines through one L1 and the product's half-spectrum
-// rows leave as whole lines from the line staging of the forward passes - the two-row form writes 32 bytes of sixteen
-// lines per store instruction and relies on a second workgroup on the same XCD to complete them in L2.
-__global__ __launch_bounds__(512, 4) void k_x_inverse_dual_reg4(float2 *__restrict__ spec1, const float2 *__restrict__ spec2,
-                                                             ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
-{
-#pragma clang fp contract(off)
-    extern __shared__ float2 lds_d4[];
-    __shared__ float smf[16];
-    constexpr int N = 2187, S = 243, I = 122;
-    const ConvGeo g = static_geo<2187>(g_);
-    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    float2 *lds = lds_d4 + half * 2 * N;
-    constexpr int groups = (2187 + 3) / 4;
-    const int z = (int)blockIdx.x / groups, y0g = ((int)blockIdx.x % groups) * 4, y0 = y0g + 2 * half;
-    const bool row0 = y0 < g.Yp, row1 = y0 + 1 < g.Yp;  // (2187 rows: the last workgroup's second half has one row)
-    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
-    const bool pair_live = tid < 2 * I;
-    int pu1 = 0, pu2 = 0;
-    const XTwiddles xt = x_twiddles_2187(ax.tw, tid);
-    if (pair_live) {
-        pu1 = ax.pos[kp] / 9;
-        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / 9;
-        int rows_c, off[9];
-        const int rb = row_base(g, min(y0 + pbi, g.Yp - 1), rows_c);
-        pair_offsets(g, S, kp, rows_c, off);
-        const int64_t rbase = (int64_t)z * g.plane + rb;
-        float2 Av[9], Bv[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            Av[i] = spec1[rbase + off[i]];
-            Bv[i] = spec2[rbase + off[i]];
-        }
-        inverse_pair_merge(lds + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
-    }
-    __syncthreads();
-    middle_inverse_2187<2>(lds, tid, xt);
-    const int64_t r0 = ((int64_t)z * g.Yp + min(y0, g.Yp - 1)) * N, r1 = r0 + (row1 ? N : 0);
-    float un0[9], un1[9];
-    if (tid < S) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            un0[q] = ep.b[r0 + tid + S * q];
-            un1[q] = ep.b[r1 + tid + S * q];
-        }
-    }
-    float mn = INFINITY, mx = -INFINITY;
-    if (tid < S) {
-        float2 w[9];
-        powers_124(w, xt.e1, xt.e2, xt.e4);
-        const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
-        float2 pk[9];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float2 v[9];  // (HTratio1 raw, HTratio2 raw) of row y0 + r at x = tid + S q
-            const float2 *row = lds + r * N + tid;
-            v[0] = row[0];
-#pragma unroll
-            for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
-            dft9<true>(v);
-            const bool live = r == 0 ? row0 : row1;
-            const bool yc = z_core && live && y0 + r >= ep.core.y0 && y0 + r < ep.core.y0 + ep.core.ny;
-            const int64_t rr = r ? r1 : r0;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int n = tid + S * q;
-                const float un = r ? un1[q] : un0[q];
-                const float h1 = v[q].x * un, h2 = v[q].y * un;  // un = 1 / update_norm
-                const float prod = (h1 - 1.0f) * (h2 - 1.0f);
-                if (live) {
-                    const float hs = h1 + h2;
-                    mn = fminf(mn, hs);
-                    mx = fmaxf(mx, hs);
-                    if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[rr + n] = hs;
-                }
-                if (r == 0) pk[q] = make_float2(prod, 0.0f);
-                else if (row1) pk[q].y = prod;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-#pragma clang fp contract(fast)
-            dft9<false>(pk);
-            float2 *orow = lds + tid;
-            orow[0] = pk[0];
-#pragma unroll
-            for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
-        }
-    }
-    mn = m3d::wave_min(mn);
-    mx = m3d::wave_max(mx);
-    if ((threadIdx.x & 63) == 0) {
-        smf[threadIdx.x >> 6] = mn;
-        smf[8 + (threadIdx.x >> 6)] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int *red = red_slot(ep.red);
-        mn = fminf(fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3])), fminf(fminf(smf[4], smf[5]), fminf(smf[6], smf[7])));
-        mx = fmaxf(fmaxf(fmaxf(smf[8], smf[9]), fmaxf(smf[10], smf[11])),
-                   fmaxf(fmaxf(smf[12], smf[13]), fmaxf(smf[14], smf[15])));
-        atomicMin(&red[0], m3d::float_key(mn));
-        atomicMax(&red[1], m3d::float_key(mx));
-    }
-    middle_forward_2187<1>(lds, tid, xt);
-    float2 c1[9], c2[9];
-    if (tid < I) forward_pair_load(lds, pu1, pu2, c1, c2);
-    __syncthreads();  // every pair has read its blocks: the first 35 KB become the line staging of all four rows
-    const int64_t zterm = (int64_t)z * g.plane;
-    if (tid < I) forward_pair_emit<true>(c1, c2, g, S, kp, spec1, zterm, y0, true, true, lds_d4, 2 * half);
-    __syncthreads();
-    unsigned rows_ok = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (y0g + r < g.Yp) rows_ok |= 1u << r;
-    store_staged_lines(lds_d4, g, spec1, zterm, y0g, rows_ok, (int)threadIdx.x, 512);
-}
-
 // ---------------------------------------------------------------- X inverse of Hu + split + two X forward transforms
 // One row pair (y, y + 1) of one core plane per workgroup; static geometry (2187 = 9 * 9 * 3 * 9) only.  LDS: two
 // rows of N complex values - T carries the packed inverse transform of the pair and then ratio1's packed forward
@@ -2234,7 +2113,6 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
                   p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&
                   p->ax.radix[2] == 3) ? 1 : 0;
-    p->dual4 = (p->xstatic && knob("M3D_FFT_DUAL4", 1)) ? 1 : 0;
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -2296,7 +2174,6 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1, false>, attr, lds_dual);
     (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0, true>, attr, lds_dual);
     (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1, true>, attr, lds_dual);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual_reg4, attr, (int)(4 * (size_t)Xp * sizeof(float2)));
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 0>, attr, (int)p->lds_x);
     (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 1>, attr, (int)p->lds_x);
@@ -2612,10 +2489,7 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
     const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
     const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
     if (p->xstatic) {
-        if (chain_forward && p->dual4)
-            hipLaunchKernelGGL(k_x_inverse_dual_reg4, dim3((unsigned)(p->Zp * ((p->Yp + 3) / 4))), dim3(512),
-                               (size_t)4 * p->Xp * sizeof(float2), st, spec1, spec2, g, p->ax, *epilogue);
-        else if (chain_forward)
+        if (chain_forward)
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, true, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, false, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
