@@ -55,6 +55,10 @@ struct AxisPlan {
 // (op_sel / op_sel_hi choose the half of each source per result lane, neg_lo / neg_hi negate a source per lane): it
 // emits v_xor + v_mov in front of the packed operation instead (27 % of the dual X pass's vector instructions in
 // round 2).  Those forms are spelled out below as one instruction each.
+// (Inline asm is opaque to the compiler's hazard recogniser: an operand must not be the direct result of a transcendental
+// instruction - v_rcp / v_log / v_sqrt ... need one wait state before a vector consumer on gfx94x/95x, which the compiler
+// inserts for its own instructions only.  Nothing here is fed that way: operands are loads, LDS reads and other packed
+// results.)
 //   result.lo = [-]src0[op_sel[0]] * src1[op_sel[1]] + src2[op_sel[2]]          (neg_lo)
 //   result.hi = [-]src0[op_sel_hi[0]] * src1[op_sel_hi[1]] + src2[op_sel_hi[2]]  (neg_hi)
 typedef float v2f __attribute__((ext_vector_type(2)));
