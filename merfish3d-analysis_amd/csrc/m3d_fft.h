@@ -62,6 +62,34 @@ struct AxisPlan {
 //   result.lo = [-]src0[op_sel[0]] * src1[op_sel[1]] + src2[op_sel[2]]          (neg_lo)
 //   result.hi = [-]src0[op_sel_hi[0]] * src1[op_sel_hi[1]] + src2[op_sel_hi[2]]  (neg_hi)
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Streaming accesses (the `nt` bit): every spectrum, OTF and volume element of a pass is touched once per launch and
+// the working set of an iteration is 70 GB, so nothing a pass reads or writes is worth keeping in L2 / the Infinity
+// Cache for the next one.  Measured on the Y passes (profiles/r03_streaming_accesses.txt): -4 % with loads AND stores
+// marked, nothing with either alone.
+__device__ __forceinline__ float4 ld_stream(const float4 *p)
+{
+    const v4f t = __builtin_nontemporal_load((const v4f *)p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st_stream(float4 *p, float4 v)
+{
+    const v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (v4f *)p);
+}
+__device__ __forceinline__ float2 ld_stream(const float2 *p)
+{
+    const v2f t = __builtin_nontemporal_load((const v2f *)p);
+    return make_float2(t.x, t.y);
+}
+__device__ __forceinline__ void st_stream(float2 *p, float2 v)
+{
+    const v2f t = {v.x, v.y};
+    __builtin_nontemporal_store(t, (v2f *)p);
+}
+__device__ __forceinline__ float ld_stream(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ v2f nv(float2 a)
 {
     v2f r = {a.x, a.y};
