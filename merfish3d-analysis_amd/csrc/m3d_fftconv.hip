@@ -766,7 +766,7 @@ __device__ __forceinline__ void store_staged_lines(const float2 *stage, const Co
         const float4 v = st4[i];
         float2 *dst = spec + zterm + rbase + ((L * rows_c + r) << 2) + 2 * (c & 1);
         if (k + 1 < g.Xc)
-            *(float4 *)dst = v;
+            st_stream((float4 *)dst, v);  // whole lines, read next by another pass: -4 % (update chain), -5 % (forward)
         else
             *dst = make_float2(v.x, v.y);
     }
