@@ -1132,9 +1132,16 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
     const int item = (g.xcdpair && b < (nblk & ~15)) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
     const int z = item / groups, y0 = (item % groups) * 2;
-    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    // static geometry: neighbouring lanes take the two rows of one frequency pair, so a load instruction covers 64
+    // contiguous bytes (both rows) of eight 128-byte lines instead of 32 bytes of sixteen
+    const int pbi = NS ? (tid & 1) : (tid >= I ? 1 : 0), kp = NS ? (tid >> 1) : tid - pbi * I;
     const bool pair_live = tid < 2 * I;
     int pu1 = 0, pu2 = 0;
+    int fu1 = 0, fu2 = 0;  // the chained forward transform's pairs: thread tid < I takes pair tid
+    if (CHAIN && tid < I) {
+        fu1 = ax.pos[tid] / 9;
+        fu2 = ax.pos[tid == 0 ? 0 : S - tid] / 9;
+    }
     XTwiddles xt;
     if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
     if (pair_live) {
@@ -1238,8 +1245,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         else middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
         if (tid < I) {
             float2 c1[9], c2[9];
-            forward_pair_load(lds_dr, pu1, pu2, c1, c2);
-            forward_pair_emit<false>(c1, c2, g, S, kp, spec1, (int64_t)z * g.plane, y0, true, row1);
+            forward_pair_load(lds_dr, fu1, fu2, c1, c2);
+            forward_pair_emit<false>(c1, c2, g, S, tid, spec1, (int64_t)z * g.plane, y0, true, row1);
         }
     }
 }
