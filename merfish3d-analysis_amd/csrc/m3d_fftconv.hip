@@ -930,7 +930,9 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
-    const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
+    // static geometry (four rows per workgroup): neighbouring lanes take the two row pairs of one frequency pair, so a
+    // load instruction touches eight 128-byte lines (64 bytes of each) instead of sixteen (32 bytes of each)
+    const int pbi = NS ? (tid & 1) : (tid >= I ? 1 : 0), kp = NS ? (tid >> 1) : tid - pbi * I;
     int u1 = 0, u2 = 0;
     XTwiddles xt;
     if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
