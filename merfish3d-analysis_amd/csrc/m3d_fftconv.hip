@@ -71,7 +71,6 @@ struct FftConvPlan {
     int xcdpair;
     int ystatic;  // the Y pass runs its static-geometry build
     int xstatic;  // the register-edge X passes run their static-geometry builds (NS = 2187)
-    int dual8;    // static geometry: the chained dual X inverse pass runs its eight-wave build (k_x_inverse_dual_w8)
 };
 
 }  // namespace m3d
@@ -1254,256 +1253,6 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     }
 }
 
-// ---------------------------------------------------------------- dual X inverse pass, eight waves per workgroup
-// The same pass as k_x_inverse_dual_reg<1, true, 2187> - same operations on the same values in the same order - with
-// its work items spread over 512 threads instead of 256, so that no thread carries more than ONE 9-point butterfly's
-// operands at a time and the kernel fits 64 registers: four workgroups per CU (35 KB of LDS each) are then 32 waves
-// instead of 16.  The 256-thread kernel is a latency chain at four waves per SIMD (47 % of its issue slots used,
-// waves in s_waitcnt / barriers 46 % of their time, profiles/r03_pmc_sq_rlgc.json).
-//   merge:    item (frequency pair k', row, block): lanes 2 j / 2 j + 1 own the blocks k' and S - k' of one pair; each
-//             loads its own block's five (four) frequencies of both spectra, forms the direct terms A + i B and the
-//             mirror terms conj(A) + i conj(B), hands the mirror terms to its neighbour (DPP) and transforms ONE block
-//   middle:   (butterfly, row) items - 486 nine-point, 1458 three-point
-//   last:     waves 0-3 row y0, waves 4-7 row y0 + 1 (one row's tail per thread); the product row of y0 + 1 crosses to
-//             the threads of y0 through the LDS slots its owner has just read, and those run the first forward stage
-//   emit:     the lane pair again: one block's last-stage butterfly per lane, mirror partners exchanged by DPP
-// Twiddles come from the table where they are used (nothing is held across stages).
-__device__ __forceinline__ float2 lane_xor1(float2 v)  // the value of lane t ^ 1 (quad_perm [1, 0, 3, 2])
-{
-    const int x = __builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0xB1, 0xF, 0xF, true);
-    const int y = __builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0xB1, 0xF, 0xF, true);
-    return make_float2(__int_as_float(x), __int_as_float(y));
-}
-template <bool INV>
-__device__ __forceinline__ void w8_stage27(float2 *lds, const float2 *__restrict__ tw, int tid, int rows)
-{
-    // radix-3 butterflies of block size 27: 729 per row, item -> (row, block, j) as x_stage27
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int i = tid + 512 * k;
-        if (i >= 729 * rows) break;
-        const int r = i >= 729 ? 1 : 0, t = i - 729 * r, blk = t / 9, j = t - blk * 9;
-        float2 *p = lds + r * 2187 + blk * 27 + j;
-        const float2 w1 = tw[81 * j], w2 = cmul(w1, w1);
-        float2 u0 = p[0], u1 = p[9], u2 = p[18];
-        if (INV) {
-            u1 = cmul_conj(u1, w1);
-            u2 = cmul_conj(u2, w2);
-            dft3<true>(u0, u1, u2);
-        } else {
-            dft3<false>(u0, u1, u2);
-            u1 = cmul(u1, w1);
-            u2 = cmul(u2, w2);
-        }
-        p[0] = u0;
-        p[9] = u1;
-        p[18] = u2;
-    }
-}
-template <bool INV>
-__device__ __forceinline__ void w8_stage243(float2 *lds, const float2 *__restrict__ tw, int tid, int rows)
-{
-    // radix-9 butterflies of block size 243: 243 per row, item -> (row, block, j) as x_stage243
-    if (tid >= 243 * rows) return;
-    const int r = tid >= 243 ? 1 : 0, t = tid - 243 * r, blk = t / 27, j = t - blk * 27;
-    float2 w[9];
-    powers_124(w, tw[9 * j], tw[18 * j], tw[36 * j]);
-    float2 *p = lds + r * 2187 + blk * 243 + j;
-    float2 v[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) v[q] = p[q * 27];
-    if (INV) {
-#pragma unroll
-        for (int q = 1; q < 9; ++q) v[q] = cmul_conj(v[q], w[q]);
-        dft9<true>(v);
-    } else {
-        dft9<false>(v);
-#pragma unroll
-        for (int q = 1; q < 9; ++q) v[q] = cmul(v[q], w[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) p[q * 27] = v[q];
-}
-
-__global__ __launch_bounds__(512, 8) void k_x_inverse_dual_w8(float2 *__restrict__ spec1, const float2 *__restrict__ spec2,
-                                                          ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
-{
-#pragma clang fp contract(off)
-    extern __shared__ float2 lds_d8[];
-    __shared__ float smf8[16];
-    constexpr int N = 2187, S = 243, I = 122;
-    const ConvGeo g = static_geo<2187>(g_);
-    const int tid = threadIdx.x;
-    const int groups = (N + 1) / 2;
-    const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
-    const int item = (g.xcdpair && b < (nblk & ~15)) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
-    const int z = item / groups, y0 = (item % groups) * 2;
-    const bool row1 = y0 + 1 < N;
-    const int64_t zterm = (int64_t)z * g.plane;
-    const float2 *__restrict__ tw = ax.tw;
-    {   // Hermitian merge + first inverse stage: lane (pair k', row, block)
-        const int half = tid & 1, prow = (tid >> 1) & 1, kp = tid >> 2;
-        if (kp < I) {  // (uniform over a lane pair, so the exchange below always finds its partner active)
-            const int kb = half ? (kp == 0 ? 0 : S - kp) : kp;  // this lane's block
-            const int pu = ax.pos[kb] / 9;
-            int rows_c;
-            const int rb = row_base(g, min(y0 + prow, N - 1), rows_c);
-            const int64_t rbase = zterm + rb;
-            float2 Av[5], Bv[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {  // (block S - k' holds four stored frequencies: its fifth load is a stand-in)
-                const int k = min(kb + S * d, g.Xc - 1);
-                const int off = tile_term(g, k, rows_c);
-                Av[d] = spec1[rbase + off];
-                Bv[d] = spec2[rbase + off];
-            }
-            float2 c[9], mir[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                c[d] = add_i(Av[d], Bv[d]);
-                mir[d] = conj_add_i_conj(Av[d], Bv[d]);
-            }
-            float2 got[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) got[d] = lane_xor1(mir[d]);
-            // block k' (k' > 0): c[8 - d] = mirror of block S - k' at d < 4;  block S - k': c[8 - d] = mirror of block
-            // k' at d < 5;  block 0 mirrors onto itself: c[9 - d] = its own mirror at 1 <= d <= 4
-            const bool self = kp == 0;
-            if (half) c[4] = got[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const float2 own = mir[d + 1], oth = got[d];  // slot 8 - d
-                c[8 - d] = make_float2(self ? own.x : oth.x, self ? own.y : oth.y);
-            }
-            if (!(half && self)) {
-                dft9<true>(c);
-                float2 *row = lds_d8 + prow * N + 9 * pu;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) row[q] = c[q];
-            }
-        }
-    }
-    __syncthreads();
-    w8_stage27<true>(lds_d8, tw, tid, 2);
-    __syncthreads();
-    w8_stage243<true>(lds_d8, tw, tid, 2);
-    __syncthreads();
-    // last inverse stage + consensus arithmetic: one row per thread
-    const int r = tid >> 8, t = tid & 255;
-    const bool tail_live = t < S;
-    float mn = INFINITY, mx = -INFINITY;
-    float prod[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) prod[q] = 0.0f;
-    if (tail_live) {
-        float2 v[9];
-        {
-            float2 w[9];
-            powers_124(w, tw[t], tw[2 * t], tw[4 * t]);
-            const float2 *row = lds_d8 + r * N + t;
-            v[0] = row[0];
-#pragma unroll
-            for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
-        }
-        dft9<true>(v);
-        const bool live = r == 0 || row1;
-        const int y = y0 + (live ? r : 0);
-        const int64_t rr = ((int64_t)z * N + y) * N;
-        const bool yc = live && z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz && y >= ep.core.y0 &&
-                        y < ep.core.y0 + ep.core.ny;
-        float un[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) un[q] = ep.b[rr + t + S * q];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int n = t + S * q;
-            const float h1 = v[q].x * un[q], h2 = v[q].y * un[q];  // un = 1 / update_norm
-            prod[q] = (h1 - 1.0f) * (h2 - 1.0f);
-            if (live) {
-                const float hs = h1 + h2;
-                mn = fminf(mn, hs);
-                mx = fmaxf(mx, hs);
-                if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[rr + n] = hs;
-            }
-        }
-        if (r == 1) {  // the product row of y0 + 1 crosses to the threads of y0 through the slots just read
-            float2 *row = lds_d8 + N + t;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) row[S * q] = make_float2(row1 ? prod[q] : 0.0f, 0.0f);
-        }
-    }
-    mn = m3d::wave_min(mn);
-    mx = m3d::wave_max(mx);
-    if ((tid & 63) == 0) {
-        smf8[tid >> 6] = mn;
-        smf8[8 + (tid >> 6)] = mx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned int *red = red_slot(ep.red);
-#pragma unroll
-        for (int wv = 1; wv < 8; ++wv) {
-            mn = fminf(mn, smf8[wv]);
-            mx = fmaxf(mx, smf8[8 + wv]);
-        }
-        atomicMin(&red[0], m3d::float_key(mn));
-        atomicMax(&red[1], m3d::float_key(mx));
-    }
-    if (r == 0 && tail_live) {
-        // first forward stage of the packed product rows (row y0, row y0 + 1)
-#pragma clang fp contract(fast)
-        float2 pk[9];
-        const float2 *other = lds_d8 + N + t;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) pk[q] = make_float2(prod[q], other[S * q].x);
-        float2 w[9];
-        powers_124(w, tw[t], tw[2 * t], tw[4 * t]);
-        dft9<false>(pk);
-        float2 *orow = lds_d8 + t;
-        orow[0] = pk[0];
-#pragma unroll
-        for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
-    }
-    __syncthreads();
-    {
-#pragma clang fp contract(fast)
-        w8_stage243<false>(lds_d8, tw, tid, 1);
-        __syncthreads();
-        w8_stage27<false>(lds_d8, tw, tid, 1);
-        __syncthreads();
-        // last forward stage + Hermitian split: lane (pair k', block)
-        const int half = tid & 1, kp = tid >> 1;
-        if (kp < I) {
-            const int kb = half ? (kp == 0 ? 0 : S - kp) : kp;
-            const int pu = ax.pos[kb] / 9;
-            float2 c[9];
-            const float2 *row = lds_d8 + 9 * pu;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) c[q] = row[q];
-            dft9<false>(c);
-            float2 got[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) got[d] = lane_xor1(c[8 - d]);
-            const bool self = kp == 0;
-            if (!(half && self)) {
-                int rows_c;
-                const int rbase = row_base(g, y0, rows_c);
-                const float2 hf = make_float2(0.5f, 0.5f);
-#pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    if (d == 4 && half) break;  // block S - k' holds four stored frequencies
-                    const float2 own = c[(9 - d) % 9];  // block 0: the mirror of S d is S (9 - d)
-                    const float2 m = make_float2(self ? own.x : got[d].x, self ? own.y : got[d].y);
-                    const float2 A = add_conj(c[d], m) * hf, B = split_odd(c[d], m) * hf;
-                    const int in_plane = rbase + tile_term(g, kb + S * d, rows_c);
-                    spec1[zterm + in_plane] = A;
-                    if (row1) spec1[zterm + in_plane + 4] = B;
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- X inverse of Hu + split + two X forward transforms
 // One row pair (y, y + 1) of one core plane per workgroup; static geometry (2187 = 9 * 9 * 3 * 9) only.  LDS: two
 // rows of N complex values - T carries the packed inverse transform of the pair and then ratio1's packed forward
@@ -2383,7 +2132,6 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
                   p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&
                   p->ax.radix[2] == 3) ? 1 : 0;
-    p->dual8 = (p->xstatic && knob("M3D_FFT_DUAL8", 0)) ? 1 : 0;  // measured slower (profiles/r03_dual_eight_waves.txt)
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -2760,9 +2508,7 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
     const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
     const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
     if (p->xstatic) {
-        if (chain_forward && p->dual8)
-            hipLaunchKernelGGL(k_x_inverse_dual_w8, grid, dim3(512), lds, st, spec1, spec2, g, p->ax, *epilogue);
-        else if (chain_forward)
+        if (chain_forward)
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, true, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, false, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);

@@ -343,38 +343,6 @@ def test_static_geometry_kernels_equal_the_generic_ones(monkeypatch):
     assert float((a[0] - b[0]).abs().max() / b[0].abs().max()) < 2e-5
 
 
-def test_eight_wave_dual_pass_equals_the_four_wave_one(monkeypatch):
-    """The chained dual X inverse pass of lateral size 2187 has two builds: 256 threads with both rows of a pair per
-    thread (k_x_inverse_dual_reg) and 512 threads with one butterfly's operands per thread (k_x_inverse_dual_w8, the
-    default).  Same operations on the same values in the same order: same iterations, same traces, and the volumes
-    agree to the last bit or, where the compiler contracts a product differently, to a rounding of one transform.
-    An odd plane count in the box and the last (single) row of the 2187 are part of every solve at this size."""
-    rl = pkg("utils.rlgc")
-    gen = torch.Generator(device=DEV).manual_seed(23)
-    shape = (22, 2140, 2140)
-    img = torch.poisson(torch.rand(shape, device=DEV, generator=gen) * 200 + 50, generator=gen).to(torch.uint16)
-    img[7, 1500:1530, 40:90] = 30000
-    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (9, 47, 47)], indexing="ij")
-    psf = torch.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2)).float()
-    out = {}
-    for eight in ("1", "0"):
-        rl.clear_rlgc_caches(clear_memory_pool=True)        # the switch is read when a plan is created
-        monkeypatch.setenv("M3D_FFT_DUAL8", eight)
-        o, info = rl.rlgc_device(img, psf, max_iterations=5, rng_seed=9)
-        out[eight] = (o.clone(), info)
-    rl.clear_rlgc_caches(clear_memory_pool=True)
-    a, b = out["1"], out["0"]
-    assert tuple(a[1].padded_shape) == (32, 2187, 2187)
-    assert (a[1].iterations, a[1].stop_reason) == (b[1].iterations, b[1].stop_reason)
-    np.testing.assert_allclose(a[1].kld_split1, b[1].kld_split1, rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(a[1].kld_image, b[1].kld_image, rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(a[1].update_min, b[1].update_min, rtol=1e-6)
-    np.testing.assert_allclose(a[1].update_max, b[1].update_max, rtol=1e-6)
-    err = float((a[0] - b[0]).abs().max() / b[0].abs().max())
-    print(f"eight-wave vs four-wave dual pass: max rel diff {err:.3e}, bit-equal {torch.equal(a[0], b[0])}")
-    assert err < 2e-6
-
-
 def test_setup_is_reused_for_the_same_psf_and_rebuilt_for_another(monkeypatch):
     """OTF / update_norm stay in the plan's workspace between runs (a tile's bits share their PSF): reusing
     them must give the bits a fresh setup gives, and a different PSF must not pick up stale volumes."""
