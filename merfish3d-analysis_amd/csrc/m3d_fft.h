@@ -363,7 +363,10 @@ __device__ __forceinline__ void dft_r(float2 *v)
 // size.  A work item = one butterfly index t for a group of G = min(batch, 4) transforms
 // (twiddles and the (block, j) split are computed once per item).  batch / G must be a
 // power of two.
-template <int R, bool INV>
+// BLOCK_LANES: items run over the blocks first (lane -> block, then j) instead of over j first: neighbouring lanes
+// are M elements apart.  For the radix-3 stage of block size 27 that is an odd stride - conflict free - where j-first
+// order reads 9 adjacent elements, skips 18 and wraps onto its own banks (two LDS cycles per access group).
+template <int R, bool INV, bool BLOCK_LANES = false>
 __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estride, int batch,
                                           int bstride, const float2 *__restrict__ tw, int tid,
                                           int nthreads, int gmax = 4)
@@ -381,7 +384,11 @@ __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estrid
         const int bg = i & (nbg - 1);
         const int t = i >> bshift;
         int blk, j;
-        if (sub > 1) {
+        if constexpr (BLOCK_LANES) {
+            const int nblk = n / M;
+            j = t / nblk;
+            blk = t - j * nblk;
+        } else if (sub > 1) {
             blk = (int)__umulhi((uint32_t)t, magic);
             j = t - blk * sub;
         } else {

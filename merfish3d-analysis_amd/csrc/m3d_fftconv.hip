@@ -511,7 +511,7 @@ __device__ __forceinline__ void edge_twiddles(float2 (&w)[9], const float2 *__re
 // L1) that the whole stage waits for - four such trips per middle pass and one per edge stage in round 2's kernels,
 // at four waves per SIMD.  A thread's butterfly indices are the same in every stage of one kind, so nine values serve
 // the whole kernel: edge stages W^(t q), q = 1, 2, 4 (t = tid), block-243 stage W^(9 j q) with j = tid % 27, block-27
-// stage W^(81 j) with j = (tid + 256 k) % 9, k < 3.  The other powers are the same products as before.
+// stage W^(81 j) with j = (tid + 256 k) / 81, k < 3.  The other powers are the same products as before.
 struct XTwiddles {
     float2 e1, e2, e4;  // edge stages
     float2 a1, a2, a4;  // block-243 stage (radix 9)
@@ -528,7 +528,7 @@ __device__ __forceinline__ XTwiddles x_twiddles_2187(const float2 *__restrict__ 
     x.a2 = tw[2 * j1];
     x.a4 = tw[4 * j1];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) x.b[k] = tw[81 * ((tid + 256 * k) % 9)];
+    for (int k = 0; k < 3; ++k) x.b[k] = tw[81 * (min(tid + 256 * k, 728) / 81)];
     return x;
 }
 __device__ __forceinline__ void powers_124(float2 (&w)[9], float2 w1, float2 w2, float2 w4)
@@ -582,7 +582,11 @@ __device__ __forceinline__ void x_stage27(float2 *lds, int tid, const XTwiddles 
     int at[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int t = min(tid + 256 * k, 728), blk = t / 9, j = t - blk * 9;
+        // item -> (j, block) with the BLOCK running along the lanes: neighbouring lanes are 27 elements apart (odd, so
+        // the 16 lanes of an LDS access group fall on 16 different bank pairs); with j along the lanes a group read
+        // nine adjacent elements, skipped eighteen and wrapped onto its own banks - every access of this stage took
+        // two LDS cycles per group (scripts/lds_banks.py, profiles/r03_lds_banks.txt)
+        const int t = min(tid + 256 * k, 728), j = t / 81, blk = t - j * 81;
         at[k] = blk * 27 + j;
 #pragma unroll
         for (int r = 0; r < NB; ++r)
@@ -662,7 +666,7 @@ __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, 
     if constexpr (NS == 2187) {
         lds_stage<9, false>(lds, 2187, 243, 1, nb, 2187, ax.tw, tid, 256, 4);
         __syncthreads();
-        lds_stage<3, false>(lds, 2187, 27, 1, nb, 2187, ax.tw, tid, 256, 4);
+        lds_stage<3, false, true>(lds, 2187, 27, 1, nb, 2187, ax.tw, tid, 256, 4);
         __syncthreads();
         return;
     }
@@ -678,7 +682,7 @@ template <int RSET, int NS = 0>
 __device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, int nb, int N, int tid, int nt, int gmax)
 {
     if constexpr (NS == 2187) {
-        lds_stage<3, true>(lds, 2187, 27, 1, nb, 2187, ax.tw, tid, 256, 4);
+        lds_stage<3, true, true>(lds, 2187, 27, 1, nb, 2187, ax.tw, tid, 256, 4);
         __syncthreads();
         lds_stage<9, true>(lds, 2187, 243, 1, nb, 2187, ax.tw, tid, 256, 4);
         __syncthreads();
