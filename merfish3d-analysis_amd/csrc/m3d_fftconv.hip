@@ -1521,6 +1521,14 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
             w[6] = cmul(w[2], w[4]);
             w[7] = cmul(w[3], w[4]);
             w[8] = cmul(w[4], w[4]);
+        } else if constexpr (R == 8) {
+            w[1] = tw[j1];
+            w[2] = tw[2 * j1];
+            w[4] = tw[4 * j1];
+            w[3] = cmul(w[1], w[2]);
+            w[5] = cmul(w[1], w[4]);
+            w[6] = cmul(w[2], w[4]);
+            w[7] = cmul(w[3], w[4]);
         } else {
             w[1] = tw[j1];
             if constexpr (R >= 3) w[2] = cmul(w[1], w[1]);
@@ -2129,7 +2137,22 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
                   ? 1 : 0;
     p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && (p->ythreads == 768 || p->ythreads == 1024) &&
                   p->gy == 4 && p->ay.nstages == 4 && p->ay.radix[0] == 9 && p->ay.radix[1] == 9 &&
-                  p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 1 : 0;
+                  p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 2187 : 0;
+    // Other common padded lengths (1024- / 1600- / 1200- / 1920-pixel images + PSF halo) get static Y kernels of
+    // their own, with radix-8 stages for the powers of two: the generic kernel runs 2048 as 4 * 4 * 4 * 4 * 4 * 2 - six
+    // LDS stages with run-time index arithmetic - and costs 1.55 x per voxel (profiles/r03_sizes.txt).  The Y axis's
+    // radix list is private to the Y passes (the spectrum only ever meets the OTF, which the same passes produce).
+    if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && p->TW == 4 && p->lch == 7 && p->gy == 4 &&
+        getenv("M3D_FFT_YT") == nullptr) {
+        static const int lists[][5] = {{2048, 8, 8, 8, 4}, {1728, 9, 8, 8, 3}, {1296, 9, 9, 4, 4}, {1152, 9, 8, 4, 4}};
+        for (const auto &l : lists)
+            if (Yp == l[0]) {
+                p->ystatic = Yp;
+                p->ay.nstages = 4;
+                for (int i = 0; i < 4; ++i) p->ay.radix[i] = l[1 + i];
+                p->rset_y = 0;  // the run-time kernels that remain reachable (deep-pad mirror pass) need radix 8
+            }
+    }
     // the static Y kernels spread (butterfly, column group) items over the threads: 972 (forward) / 486 (inverse) items
     // in the radix-9 stages, one round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
     if (p->ystatic && getenv("M3D_FFT_YT") == nullptr) p->ythreads = 1024;
@@ -2306,12 +2329,20 @@ template <bool INV>
 static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, int nz, hipStream_t st)
 {
     const dim3 grid((unsigned)(nz * p->nT)), block(p->ythreads);
-    if (p->ystatic) {
+    if (p->ystatic == 2187) {
         if (p->ythreads == 1024)
             hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
         else
             hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 768>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
-    } else if (p->rset_y)
+    } else if (p->ystatic == 2048)
+        hipLaunchKernelGGL((k_y_pass_static<INV, 2048, 8, 8, 8, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->ystatic == 1728)
+        hipLaunchKernelGGL((k_y_pass_static<INV, 1728, 9, 8, 8, 3, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->ystatic == 1296)
+        hipLaunchKernelGGL((k_y_pass_static<INV, 1296, 9, 9, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->ystatic == 1152)
+        hipLaunchKernelGGL((k_y_pass_static<INV, 1152, 9, 8, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<INV, 1>), grid, block, p->lds_y, st, spec, g, p->ay);
     else
         hipLaunchKernelGGL((k_y_pass<INV, 0>), grid, block, p->lds_y, st, spec, g, p->ay);
@@ -2350,12 +2381,16 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         if (!x_done) launch_x_forward(p, src, spec, g, groups, st);  // x_done: chained from the update pass
         if (log && log->mark(EventLog::kXF)) return M3D_ERR_HIP;
         const bool one_reflection = g.mir.y0 <= g.mir.ny && p->Yp - (g.mir.y0 + g.mir.ny) <= g.mir.ny;
-        if (p->ystatic && one_reflection && p->ythreads == 1024)
-            hipLaunchKernelGGL((k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 1024>), dim3(yplanes * (unsigned)p->nT),
-                               dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);
-        else if (p->ystatic && one_reflection)
-            hipLaunchKernelGGL((k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>), dim3(yplanes * (unsigned)p->nT),
-                               dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);
+#define M3D_LAUNCH_YMS(YP, R0, R1, R2, R3, NT)                                                                          \
+    hipLaunchKernelGGL((k_y_forward_mirror_static<YP, R0, R1, R2, R3, 7, NT>), dim3(yplanes * (unsigned)p->nT),           \
+                       dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw)
+        if (p->ystatic == 2187 && one_reflection && p->ythreads == 1024) M3D_LAUNCH_YMS(2187, 9, 9, 9, 3, 1024);
+        else if (p->ystatic == 2187 && one_reflection) M3D_LAUNCH_YMS(2187, 9, 9, 9, 3, 768);
+        else if (p->ystatic == 2048 && one_reflection) M3D_LAUNCH_YMS(2048, 8, 8, 8, 4, 1024);
+        else if (p->ystatic == 1728 && one_reflection) M3D_LAUNCH_YMS(1728, 9, 8, 8, 3, 1024);
+        else if (p->ystatic == 1296 && one_reflection) M3D_LAUNCH_YMS(1296, 9, 9, 4, 4, 1024);
+        else if (p->ystatic == 1152 && one_reflection) M3D_LAUNCH_YMS(1152, 9, 8, 4, 4, 1024);
+#undef M3D_LAUNCH_YMS
         else if (p->rset_y)
             hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
         else

@@ -343,6 +343,33 @@ def test_static_geometry_kernels_equal_the_generic_ones(monkeypatch):
     assert float((a[0] - b[0]).abs().max() / b[0].abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("ly,yp", [(2002, 2048), (1680, 1728), (1250, 1296), (1100, 1152)])
+def test_static_y_kernels_of_other_lengths_equal_the_generic_ones(monkeypatch, ly, yp):
+    """Padded Y lengths 2048 / 1728 / 1296 / 1152 run static Y kernels with their own radix lists (8 8 8 4, 9 8 8 3,
+    9 9 4 4, 9 8 4 4: forward, inverse with cropped output, the mirrored forward pass); M3D_FFT_YSTATIC=0 sends the same
+    solve through the run-time kernels (radix list 4 4 4 4 4 2 for 2048, ...) that the oracle comparisons pin: same
+    iterations, KL traces and volume to the float32 rounding of a transform."""
+    rl = pkg("utils.rlgc")
+    gen = torch.Generator(device=DEV).manual_seed(ly)
+    shape = (22, ly, 70)
+    img = torch.poisson(torch.rand(shape, device=DEV, generator=gen) * 300 + 60, generator=gen).to(torch.uint16)
+    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (9, 47, 9)], indexing="ij")
+    psf = torch.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.8) ** 2 + (xx / 1.4) ** 2)).float()
+    out = {}
+    for static in ("1", "0"):
+        rl.clear_rlgc_caches(clear_memory_pool=True)        # the switch is read when a plan is created
+        monkeypatch.setenv("M3D_FFT_YSTATIC", static)
+        o, info = rl.rlgc_device(img, psf, max_iterations=5, rng_seed=4)
+        out[static] = (o.clone(), info)
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+    a, b = out["1"], out["0"]
+    assert tuple(a[1].padded_shape) == (32, yp, 81)
+    assert (a[1].iterations, a[1].stop_reason) == (b[1].iterations, b[1].stop_reason)
+    np.testing.assert_allclose(a[1].kld_split1, b[1].kld_split1, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(a[1].kld_image, b[1].kld_image, rtol=1e-5, atol=1e-8)
+    assert float((a[0] - b[0]).abs().max() / b[0].abs().max()) < 2e-5
+
+
 def test_setup_is_reused_for_the_same_psf_and_rebuilt_for_another(monkeypatch):
     """OTF / update_norm stay in the plan's workspace between runs (a tile's bits share their PSF): reusing
     them must give the bits a fresh setup gives, and a different PSF must not pick up stale volumes."""

@@ -73,7 +73,9 @@ def test_pad_psf_places_every_sample_where_the_reference_does(psf_shape, shape, 
         assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("shape", [(16, 36, 48), (8, 27, 32), (32, 81, 64), (64, 36, 48), (128, 27, 32), (256, 27, 32), (48, 32, 36)])
+@pytest.mark.parametrize("shape", [(16, 36, 48), (8, 27, 32), (32, 81, 64), (64, 36, 48), (128, 27, 32), (256, 27, 32), (48, 32, 36),
+                                   # Y lengths with static Y kernels of their own (radix 8 / 4 stages)
+                                   (32, 2048, 36), (16, 1728, 27), (16, 1296, 32), (16, 1152, 36)])
 def test_fft_conv_with_transfer_function_views(shape):
     rl = pkg("utils.rlgc")
     rng = np.random.default_rng(2)
