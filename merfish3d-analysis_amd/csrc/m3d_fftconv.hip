@@ -2010,7 +2010,10 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis
     // Z axis (short power-of-two transforms, k_z_conv<2>): as few radix-8 stages as bring the stage count
     // down to ceil(log2(n) / 3) - 128 = 8 * 4 * 4 has three barriers per transform instead of four
     // (measured 1.93 -> 1.71 ms); M3D_FFT_Z_RADIX4=1 keeps 4, 4, 4, 2.
-    if (z_axis && small_pow2 && getenv("M3D_FFT_Z_RADIX4") == nullptr) {
+    // X axis without register edge stages (in-LDS kernels): the same rule - 2048 = 8 * 8 * 8 * 4 is four LDS stages
+    // per transform instead of the six of 4 * 4 * 4 * 4 * 4 * 2 (M3D_FFT_X_RADIX4=1 keeps the radix-4 lists)
+    const bool x_eights = x_axis && !nine_last && getenv("M3D_FFT_X_RADIX4") == nullptr;
+    if ((x_eights || z_axis) && small_pow2 && getenv("M3D_FFT_Z_RADIX4") == nullptr) {
         const int best = (c2 + 2) / 3;
         int n8 = 0;
         while ((c2 - 3 * n8 + 1) / 2 + n8 > best) ++n8;
@@ -2359,7 +2362,9 @@ static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spe
             hipLaunchKernelGGL(k_x_forward_reg<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
         else
             hipLaunchKernelGGL(k_x_forward_reg<0>, grid, block, p->lds_x, st, src, spec, g, p->ax);
-    } else if (p->rset_x)
+    } else if (p->rset_x == 2)
+        hipLaunchKernelGGL(k_x_forward<2>, grid, block, p->lds_x, st, src, spec, g, p->ax);
+    else if (p->rset_x)
         hipLaunchKernelGGL(k_x_forward<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
     else
         hipLaunchKernelGGL(k_x_forward<0>, grid, block, p->lds_x, st, src, spec, g, p->ax);
@@ -2563,11 +2568,15 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
         }
 #undef M3D_LAUNCH_XD
     } else if (chain_forward) {
-        if (p->rset_x)
+        if (p->rset_x == 2)
+            hipLaunchKernelGGL((k_x_inverse_dual<2, true>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+        else if (p->rset_x)
             hipLaunchKernelGGL((k_x_inverse_dual<1, true>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
             hipLaunchKernelGGL((k_x_inverse_dual<0, true>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
-    } else if (p->rset_x)
+    } else if (p->rset_x == 2)
+        hipLaunchKernelGGL((k_x_inverse_dual<2, false>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+    else if (p->rset_x)
         hipLaunchKernelGGL((k_x_inverse_dual<1, false>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     else
         hipLaunchKernelGGL((k_x_inverse_dual<0, false>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
@@ -2615,6 +2624,10 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
             if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XIR(0, 2);
             else M3D_LAUNCH_XIR(0, 0);
         }
+    } else if (p->rset_x == 2) {
+        if (ep.kind == ConvEpilogue::kConsensus) M3D_LAUNCH_XI(2, 1);
+        else if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XI(2, 2);
+        else M3D_LAUNCH_XI(2, 0);
     } else
     if (p->rset_x) {
         if (ep.kind == ConvEpilogue::kConsensus) M3D_LAUNCH_XI(1, 1);
