@@ -493,9 +493,10 @@ __global__ __launch_bounds__(512) void k_x_inverse_dual(float2 *__restrict__ spe
 //     reversed position of a block is pos[k'] / 9 - two table loads per thread instead of two per element.
 // LDS passes per transform: 1 write + (stages - 2) read-modify-writes + 1 read (2187: 3 + 3 instead of 5 + 5), three
 // barriers instead of five.
+template <int R = 9>
 __device__ __forceinline__ void edge_twiddles(float2 (&w)[9], const float2 *__restrict__ tw, int t)
 {
-    // W_N^(t q), q < 9: powers 1, 2, 4 from the table (8 t < N), the rest by products - as lds_stage<9>
+    // W_N^(t q), q < R: powers 1, 2, 4 from the table (8 t < N), the rest by products - as lds_stage<9>
     w[1] = tw[t];
     w[2] = tw[2 * t];
     w[4] = tw[4 * t];
@@ -503,7 +504,16 @@ __device__ __forceinline__ void edge_twiddles(float2 (&w)[9], const float2 *__re
     w[5] = cmul(w[1], w[4]);
     w[6] = cmul(w[2], w[4]);
     w[7] = cmul(w[3], w[4]);
-    w[8] = cmul(w[4], w[4]);
+    if constexpr (R == 9) w[8] = cmul(w[4], w[4]);
+}
+// The edge butterfly of a register-edge X pass: radix 9 (lengths 81 m) or radix 8 (lengths 64 m; round 3).  For R = 8
+// the arrays keep nine slots: the pair (k', S - k') of 8-blocks again holds nine stored frequencies at most - five of
+// block 0 (S d, d <= 4: the last is the Nyquist frequency), else four of block k' and four of block S - k'.
+template <int R, bool INV>
+__device__ __forceinline__ void edge_dft(float2 *v)
+{
+    if constexpr (R == 9) dft9<INV>(v);
+    else dft8<INV>(v);
 }
 
 // The static X kernels (N = 2187 = 9 * 9 * 3 * 9 at 256 threads) request every twiddle they will need when they start,
@@ -670,7 +680,7 @@ __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, 
         __syncthreads();
         return;
     }
-    int M = N / 9;
+    int M = N / ax.radix[0];
     for (int s = 1; s < ax.nstages - 1; ++s) {
         const int r = ax.radix[s];
         lds_stage_r<false, RSET>(r, lds, N, M, 1, nb, N, ax.tw, tid, nt, gmax);
@@ -688,7 +698,7 @@ __device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, 
         __syncthreads();
         return;
     }
-    int M = 9;
+    int M = ax.radix[0];  // (= the last stage's radix: the edge stages share theirs)
     for (int s = ax.nstages - 2; s >= 1; --s) {
         const int r = ax.radix[s];
         M *= r;
@@ -710,19 +720,20 @@ __device__ __forceinline__ int stage_slot(int k, int r)
 }
 
 // Last forward stage for the pair of 9-blocks (k', S - k'): both blocks read from LDS and transformed in registers.
+template <int R = 9>
 __device__ __forceinline__ void forward_pair_load(const float2 *row, int u1, int u2, float2 (&c1)[9], float2 (&c2)[9])
 {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) c1[q] = row[9 * u1 + q];
+    for (int q = 0; q < R; ++q) c1[q] = row[R * u1 + q];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) c2[q] = row[9 * u2 + q];
-    dft9<false>(c1);
-    dft9<false>(c2);
+    for (int q = 0; q < R; ++q) c2[q] = row[R * u2 + q];
+    edge_dft<R, false>(c1);
+    edge_dft<R, false>(c2);
 }
 
 // Hermitian split of the pair: A (first packed real row) and B for the nine frequencies k < Xc of the pair, written
 // to the tiled spectrum rows ya / ya + 1 directly, or (STAGED) into the block's line staging at rows r0 / r0 + 1.
-template <bool STAGED = false>
+template <bool STAGED = false, int R = 9>
 __device__ __forceinline__ void forward_pair_emit(const float2 (&c1)[9], const float2 (&c2)[9], const ConvGeo &g, int S,
                                                   int kp, float2 *__restrict__ spec, int64_t zterm, int ya, bool wa,
                                                   bool wb, float2 *stage = nullptr, int r0 = 0)
@@ -746,12 +757,13 @@ __device__ __forceinline__ void forward_pair_emit(const float2 (&c1)[9], const f
 #pragma unroll
     for (int d = 0; d < 5; ++d) {  // selected by value: a conditional on the array elements themselves becomes a
                                    // pointer select and sends both arrays to scratch
-        const float2 m0 = c1[(9 - d) % 9], m1 = c2[8 - d];
+        if (R == 8 && d == 4 && kp != 0) break;  // radix 8: k' + 4 S lies beyond the Nyquist frequency unless k' = 0
+        const float2 m0 = c1[(R - d) % R], m1 = c2[(R - 1 - d) % R];
         put(kp + S * d, c1[d], make_float2(kp == 0 ? m0.x : m1.x, kp == 0 ? m0.y : m1.y));
     }
     if (k2p != kp) {
 #pragma unroll
-        for (int d = 0; d < 4; ++d) put(k2p + S * d, c2[d], c1[8 - d]);
+        for (int d = 0; d < 4; ++d) put(k2p + S * d, c2[d], c1[R - 1 - d]);
     }
 }
 
@@ -778,6 +790,7 @@ __device__ __forceinline__ void store_staged_lines(const float2 *stage, const Co
 
 // Hermitian merge + first inverse stage for the pair (k', S - k'): C = A + i B at the nine frequencies k < Xc of the
 // pair and conj(A) + i conj(B) at their mirrors, 9-point inverse butterflies, both blocks written to LDS.
+template <int R = 9>
 __device__ __forceinline__ void inverse_pair_merge(float2 *row, int S, int N, int kp, int u1, int u2,
                                                    const float2 (&Av)[9], const float2 (&Bv)[9])
 {
@@ -786,14 +799,15 @@ __device__ __forceinline__ void inverse_pair_merge(float2 *row, int S, int N, in
     const int k2p = kp == 0 ? 0 : S - kp;
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
+        if (R == 8 && d == 4 && kp != 0) break;  // radix 8: block k' > 0 holds four stored frequencies
         const float2 A = Av[d], B = Bv[d];
         const int k = kp + S * d;
         c1[d] = add_i(A, B);
         const float2 mir = conj_add_i_conj(A, B);
         if (kp == 0) {
-            if (d != 0) c1[9 - d] = mir;
+            if (d != 0 && 2 * d != R) c1[R - d] = mir;  // (radix 8: S * 4 is the Nyquist frequency, its own mirror)
         } else if (2 * k != N) {
-            c2[8 - d] = mir;
+            c2[R - 1 - d] = mir;
         }
     }
     if (k2p != kp) {
@@ -801,18 +815,18 @@ __device__ __forceinline__ void inverse_pair_merge(float2 *row, int S, int N, in
         for (int d = 0; d < 4; ++d) {
             const float2 A = Av[5 + d], B = Bv[5 + d];
             c2[d] = add_i(A, B);
-            c1[8 - d] = conj_add_i_conj(A, B);
+            c1[R - 1 - d] = conj_add_i_conj(A, B);
         }
-        dft9<true>(c2);
+        edge_dft<R, true>(c2);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) row[9 * u2 + q] = c2[q];
-    } else if (kp != 0) {  // k' = S / 2 (even S): the block mirrors onto itself, d <-> 8 - d
+        for (int q = 0; q < R; ++q) row[R * u2 + q] = c2[q];
+    } else if (kp != 0) {  // k' = S / 2 (even S): the block mirrors onto itself, d <-> R - 1 - d
 #pragma unroll
-        for (int d = 0; d < 4; ++d) c1[8 - d] = c2[8 - d];
+        for (int d = 0; d < 4; ++d) c1[R - 1 - d] = c2[R - 1 - d];
     }
-    dft9<true>(c1);
+    edge_dft<R, true>(c1);
 #pragma unroll
-    for (int q = 0; q < 9; ++q) row[9 * u1 + q] = c1[q];
+    for (int q = 0; q < R; ++q) row[R * u1 + q] = c1[q];
 }
 
 // spectrum element offsets of the pair's nine frequencies (row term excluded): [0..4] block k', [5..8] block S - k'
@@ -820,22 +834,24 @@ __device__ __forceinline__ void pair_offsets(const ConvGeo &g, int S, int kp, in
 {
     const int k2p = kp == 0 ? 0 : S - kp;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) off[d] = tile_term(g, kp + S * d, rows_c);
+    for (int d = 0; d < 5; ++d) off[d] = tile_term(g, min(kp + S * d, g.Xc - 1), rows_c);  // (radix 8, k' > 0: the
+                                                                                         // fifth is a stand-in)
 #pragma unroll
     for (int d = 0; d < 4; ++d) off[5 + d] = tile_term(g, k2p + S * d, rows_c);  // k2p == kp: loaded but unused
 }
 
-template <int RSET, int NS = 0>
-__global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restrict__ src, float2 *__restrict__ spec,
+template <int RSET, int NS = 0, int R = 9>
+__global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_forward_reg(const float *__restrict__ src, float2 *__restrict__ spec,
                                                       ConvGeo g_, AxisPlan ax)
 {
+    static_assert(R == 9 || (R == 8 && NS == 0), "edge radix 9, or 8 with run-time geometry");
     extern __shared__ float2 lds_fr[];
     const ConvGeo g = static_geo<NS>(g_);
     const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
     const int yg0 = (g.in.y0 / g.RB) * g.RB, y_hi = g.in.y0 + g.in.ny, x_hi = g.in.x0 + g.in.nx;
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.in.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
-    const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
+    const int nb = g.RB / 2, N = g.Xp, S = N / R, I = S / 2 + 1;
     // the pair item of the last stage: its two block positions are requested now, used three barriers later
     const int pbi = tid >= I ? 1 : 0, kp = tid - pbi * I;
     const bool pair_live = tid < nb * I;
@@ -849,7 +865,7 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
     if (tid < S) {
         float2 w[9];
         if constexpr (NS == 2187) powers_124(w, xt.e1, xt.e2, xt.e4);
-        else edge_twiddles(w, ax.tw, tid);
+        else edge_twiddles<R>(w, ax.tw, tid);
         const int zs = g.mirror == 1 ? sym_src(z, g.mir.z0, g.mir.nz) : z;
         for (int bi = 0; bi < nb; ++bi) {
             const int ya = y0 + 2 * bi, yb = ya + 1;
@@ -860,7 +876,7 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
             const float *rbp = src + ((int64_t)zs * g.Yp + ybs) * N;
             float a[9], b[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < R; ++q) {
                 int n = tid + S * q;
                 if (g.mirror) n = sym_src(n, g.mir.x0, g.mir.nx);
                 else n = min(max(n, g.in.x0), x_hi - 1);
@@ -869,16 +885,16 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
             }
             float2 v[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < R; ++q) {
                 const int n = tid + S * q;
                 const bool vx = g.mirror || (n >= g.in.x0 && n < x_hi);
                 v[q] = make_float2(va && vx ? a[q] : 0.0f, vb && vx ? b[q] : 0.0f);
             }
-            dft9<false>(v);
+            edge_dft<R, false>(v);
             float2 *row = lds_fr + bi * N + tid;
             row[0] = v[0];
 #pragma unroll
-            for (int q = 1; q < 9; ++q) row[S * q] = cmul(v[q], w[q]);
+            for (int q = 1; q < R; ++q) row[S * q] = cmul(v[q], w[q]);
         }
     }
     __syncthreads();
@@ -886,12 +902,12 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
     else middle_forward<RSET, NS>(lds_fr, ax, nb, N, tid, nt, g.GX);
     {
         float2 c1[9], c2[9];
-        if (pair_live) forward_pair_load(lds_fr + pbi * N, pu1 / 9, pu2 / 9, c1, c2);
+        if (pair_live) forward_pair_load<R>(lds_fr + pbi * N, pu1 / R, pu2 / R, c1, c2);
         const int ya = y0 + 2 * pbi;
         const int64_t zterm = (int64_t)z * g.plane;
         if (g.TW == 4 && g.RB == 4) {
             __syncthreads();  // every pair has read its blocks: the buffer becomes the line staging
-            if (pair_live) forward_pair_emit<true>(c1, c2, g, S, kp, spec, zterm, ya, true, true, lds_fr, 2 * pbi);
+            if (pair_live) forward_pair_emit<true, R>(c1, c2, g, S, kp, spec, zterm, ya, true, true, lds_fr, 2 * pbi);
             __syncthreads();
             unsigned rows_ok = 0;
 #pragma unroll
@@ -899,8 +915,8 @@ __global__ __launch_bounds__(256, 4) void k_x_forward_reg(const float *__restric
                 if (y0 + r >= g.in.y0 && y0 + r < y_hi) rows_ok |= 1u << r;
             store_staged_lines(lds_fr, g, spec, zterm, y0, rows_ok, tid, nt);
         } else if (pair_live) {
-            forward_pair_emit<false>(c1, c2, g, S, kp, spec, zterm, ya, ya >= g.in.y0 && ya < y_hi,
-                                     ya + 1 >= g.in.y0 && ya + 1 < y_hi);
+            forward_pair_emit<false, R>(c1, c2, g, S, kp, spec, zterm, ya, ya >= g.in.y0 && ya < y_hi,
+                                        ya + 1 >= g.in.y0 && ya + 1 < y_hi);
         }
     }
 }
@@ -919,21 +935,22 @@ template <>
 struct SpecArg<true> {
     typedef float2 *type;
 };
-template <int RSET, int EPI, int NS = 0, bool CHAIN = false>
-__global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN>::type spec, float *__restrict__ dst,
+template <int RSET, int EPI, int NS = 0, bool CHAIN = false, int R = 9>
+__global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN>::type spec, float *__restrict__ dst,
                                                       ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
     static_assert(!CHAIN || (EPI == m3d::ConvEpilogue::kUpdate && NS == 2187), "chain: update epilogue, static geometry");
+    static_assert(R == 9 || (R == 8 && NS == 0), "edge radix 9, or 8 with run-time geometry");
     extern __shared__ float2 lds_ir[];
-    __shared__ float smf[8];
-    __shared__ unsigned long long smu[4];
+    __shared__ float smf[10];
+    __shared__ unsigned long long smu[5];
     const ConvGeo g = static_geo<NS>(g_);
     const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
     const int yg0 = (g.out.y0 / g.RB) * g.RB, y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
-    const int nb = g.RB / 2, N = g.Xp, S = N / 9, I = S / 2 + 1;
+    const int nb = g.RB / 2, N = g.Xp, S = N / R, I = S / 2 + 1;
     // static geometry (four rows per workgroup): neighbouring lanes take the two row pairs of one frequency pair, so a
     // load instruction touches eight 128-byte lines (64 bytes of each) instead of sixteen (32 bytes of each)
     const int pbi = NS ? (tid & 1) : (tid >= I ? 1 : 0), kp = NS ? (tid >> 1) : tid - pbi * I;
@@ -968,7 +985,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
                 if (!vb) Bv[i] = make_float2(0.f, 0.f);
             }
         }
-        inverse_pair_merge(lds_ir + pbi * N, S, N, kp, u1 / 9, u2 / 9, Av, Bv);
+        inverse_pair_merge<R>(lds_ir + pbi * N, S, N, kp, u1 / R, u2 / R, Av, Bv);
     }
     __syncthreads();
     if constexpr (NS == 2187) middle_inverse_2187<2>(lds_ir, tid, xt);
@@ -979,7 +996,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
         float2 w[9];
         // (the chained update pass is at its register limit: its edge twiddles come from the table where they are used)
         if constexpr (NS == 2187 && !CHAIN) powers_124(w, xt.e1, xt.e2, xt.e4);
-        else edge_twiddles(w, ax.tw, tid);
+        else edge_twiddles<R>(w, ax.tw, tid);
         for (int bi = 0; bi < nb; ++bi) {
             const int yr[2] = {y0 + 2 * bi, y0 + 2 * bi + 1};
             bool valid[2];
@@ -996,7 +1013,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
+                    for (int q = 0; q < R; ++q) {
                         const int n = min(max(tid + S * q, g.out.x0), x_hi - 1);
                         ava[r][q] = ep.a[rowo[r] + n];
                         bva[r][q] = ep.b[rowo[r] + n];
@@ -1006,8 +1023,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
             const float2 *row = lds_ir + bi * N + tid;
             v[0] = row[0];
 #pragma unroll
-            for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
-            dft9<true>(v);
+            for (int q = 1; q < R; ++q) v[q] = cmul_conj(row[S * q], w[q]);
+            edge_dft<R, true>(v);
             float2 pk[9];  // CHAIN: (new row 2 bi, new row 2 bi + 1) at x = tid + S q; zero outside the core
 #pragma unroll
             for (int q = 0; q < 9; ++q) pk[q] = make_float2(0.f, 0.f);
@@ -1017,13 +1034,13 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
                 float av[9], bv[9];
                 if constexpr (EPI != m3d::ConvEpilogue::kNone) {
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) {
+                    for (int q = 0; q < R; ++q) {
                         av[q] = ava[r][q];
                         bv[q] = bva[r][q];
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 9; ++q) {
+                for (int q = 0; q < R; ++q) {
                     const int n = tid + S * q;
                     if (n < g.out.x0 || n >= x_hi) continue;
                     const float c = r ? v[q].y : v[q].x;
@@ -1102,14 +1119,14 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
         if ((tid & 63) == 0) {
             smu[tid >> 6] = upw;
             smf[tid >> 6] = mx;
-            smf[4 + (tid >> 6)] = dmax;
+            smf[5 + (tid >> 6)] = dmax;
         }
         __syncthreads();
-        if (tid == 0) {
+        if (tid == 0) {  // (a fifth wave - radix-8 edges, S = 256 - holds no element: tid >= S)
             unsigned int *red = red_slot(ep.red);
             const unsigned long long total = smu[0] + smu[1] + smu[2] + smu[3];
             mx = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
-            dmax = fmaxf(fmaxf(smf[4], smf[5]), fmaxf(smf[6], smf[7]));
+            dmax = fmaxf(fmaxf(smf[5], smf[6]), fmaxf(smf[7], smf[8]));
             if (total) atomicAdd((unsigned long long *)red, total);
             atomicMax(&red[2], m3d::float_key(mx));
             atomicMax(&red[3], __float_as_uint(dmax));
@@ -1120,17 +1137,18 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN
 // Dual X inverse pass (two spectra -> HTratio1, HTratio2 of two rows) with the consensus arithmetic in registers and,
 // CHAIN, the product's X forward transform started from the same registers: the element the last inverse stage hands
 // thread t at x = t + S q is the element the first forward stage takes from it.
-template <int RSET, bool CHAIN, int NS = 0>
-__global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
+template <int RSET, bool CHAIN, int NS = 0, int R = 9>
+__global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
                                                            const float2 *__restrict__ spec2, ConvGeo g_, AxisPlan ax,
                                                            m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
+    static_assert(R == 9 || (R == 8 && NS == 0), "edge radix 9, or 8 with run-time geometry");
     extern __shared__ float2 lds_dr[];
-    __shared__ float smf[8];
+    __shared__ float smf[10];
     const ConvGeo g = static_geo<NS>(g_);
     const int tid = threadIdx.x, nt = NS ? 256 : blockDim.x;
-    const int N = g.Xp, S = N / 9, I = S / 2 + 1;
+    const int N = g.Xp, S = N / R, I = S / 2 + 1;
     const int groups = (g.Yp + 1) / 2;
     // Two consecutive row pairs share every 128-byte line of the tiled spectra (four rows x 32 bytes).  Workgroups b and
     // b + 8 land on the same XCD, so inside each group of 16 the item order is permuted to give those two workgroups the
@@ -1145,14 +1163,14 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     int pu1 = 0, pu2 = 0;
     int fu1 = 0, fu2 = 0;  // the chained forward transform's pairs: thread tid < I takes pair tid
     if (CHAIN && tid < I) {
-        fu1 = ax.pos[tid] / 9;
-        fu2 = ax.pos[tid == 0 ? 0 : S - tid] / 9;
+        fu1 = ax.pos[tid] / R;
+        fu2 = ax.pos[tid == 0 ? 0 : S - tid] / R;
     }
     XTwiddles xt;
     if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
     if (pair_live) {
-        pu1 = ax.pos[kp] / 9;
-        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / 9;
+        pu1 = ax.pos[kp] / R;
+        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / R;
         int rows_c, off[9];
         const int rb = row_base(g, min(y0 + pbi, g.Yp - 1), rows_c);
         pair_offsets(g, S, kp, rows_c, off);
@@ -1163,7 +1181,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             Av[i] = spec1[rbase + off[i]];
             Bv[i] = spec2[rbase + off[i]];
         }
-        inverse_pair_merge(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
+        inverse_pair_merge<R>(lds_dr + pbi * N, S, N, kp, pu1, pu2, Av, Bv);
     }
     __syncthreads();
     if constexpr (NS == 2187) middle_inverse_2187<2>(lds_dr, tid, xt);
@@ -1176,7 +1194,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     float un0[9], un1[9];
     if (tid < S) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
+        for (int q = 0; q < R; ++q) {
             un0[q] = ep.b[r0 + tid + S * q];
             un1[q] = ep.b[r1 + tid + S * q];
         }
@@ -1185,7 +1203,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     if (tid < S) {
         float2 w[9];
         if constexpr (NS == 2187) powers_124(w, xt.e1, xt.e2, xt.e4);
-        else edge_twiddles(w, ax.tw, tid);
+        else edge_twiddles<R>(w, ax.tw, tid);
         const bool z_core = z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz;
         float2 pk[9];
         // one row after the other: both rows' butterflies in flight at once cost 40 registers more than there are
@@ -1195,13 +1213,13 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             const float2 *row = lds_dr + r * N + tid;
             v[0] = row[0];
 #pragma unroll
-            for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
-            dft9<true>(v);
+            for (int q = 1; q < R; ++q) v[q] = cmul_conj(row[S * q], w[q]);
+            edge_dft<R, true>(v);
             const bool live = r == 0 || row1;
             const bool yc = z_core && live && y0 + r >= ep.core.y0 && y0 + r < ep.core.y0 + ep.core.ny;
             const int64_t rr = r ? r1 : r0;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < R; ++q) {
                 const int n = tid + S * q;
                 const float un = r ? un1[q] : un0[q];
                 const float h1 = v[q].x * un, h2 = v[q].y * un;  // un = 1 / update_norm
@@ -1222,11 +1240,11 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
             // first forward stage of the packed product rows, from the registers that just produced them; the LDS
             // slots written are the ones this thread read above
 #pragma clang fp contract(fast)
-            dft9<false>(pk);
+            edge_dft<R, false>(pk);
             float2 *orow = lds_dr + tid;
             orow[0] = pk[0];
 #pragma unroll
-            for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
+            for (int q = 1; q < R; ++q) orow[S * q] = cmul(pk[q], w[q]);
         }
     }
     // per-wave extrema ride the barrier the chained forward needs anyway
@@ -1234,13 +1252,13 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
     mx = m3d::wave_max(mx);
     if ((tid & 63) == 0) {
         smf[tid >> 6] = mn;
-        smf[4 + (tid >> 6)] = mx;
+        smf[5 + (tid >> 6)] = mx;
     }
     __syncthreads();
     if (tid == 0) {
         unsigned int *red = red_slot(ep.red);
-        mn = fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3]));
-        mx = fmaxf(fmaxf(smf[4], smf[5]), fmaxf(smf[6], smf[7]));
+        mn = fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3]));  // (a fifth wave - radix-8 edges, S = 256 - holds no
+        mx = fmaxf(fmaxf(smf[5], smf[6]), fmaxf(smf[7], smf[8]));  //  element: tid >= S)
         {
             atomicMin(&red[0], m3d::float_key(mn));
             atomicMax(&red[1], m3d::float_key(mx));
@@ -1251,8 +1269,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_dual_reg(float2 *__restric
         else middle_forward<RSET, NS>(lds_dr, ax, 1, N, tid, nt, g.GX);
         if (tid < I) {
             float2 c1[9], c2[9];
-            forward_pair_load(lds_dr, fu1, fu2, c1, c2);
-            forward_pair_emit<false>(c1, c2, g, S, tid, spec1, (int64_t)z * g.plane, y0, true, row1);
+            forward_pair_load<R>(lds_dr, fu1, fu2, c1, c2);
+            forward_pair_emit<false, R>(c1, c2, g, S, tid, spec1, (int64_t)z * g.plane, y0, true, row1);
         }
     }
 }
@@ -2004,16 +2022,25 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis
     // X axis with two or more radix-9 stages: one of them goes last, so that both outer stages are radix 9 and can
     // run in registers (k_x_forward_reg / k_x_inverse_reg)
     const bool nine_last = x_axis && c3 >= 4 && getenv("M3D_FFT_XREG_ORDER") == nullptr;
+    static const bool small_pow2 = getenv("M3D_FFT_BIG_RADIX") == nullptr;  // 4,4,4,2 beat 16,8 (VGPRs)
+    // X axis of a length 64 m <= 2048 that has no two radix-9 stages (2048, 1728, 1536, 1152, 1024, 576, ...): a radix-8
+    // stage first and last, which the same register-edge kernels run (edge radix 8; M3D_FFT_XREG8=0 disables)
+    const bool eight_edges = x_axis && !nine_last && c2 >= 6 && n / 8 <= 256 && small_pow2 &&
+                             !(getenv("M3D_FFT_XREG8") && atoi(getenv("M3D_FFT_XREG8")) == 0);
+    if (eight_edges) {
+        radix[s++] = 8;
+        c2 -= 6;
+    }
     for (int i = 0; i < c3 / 2 - (nine_last ? 1 : 0); ++i) radix[s++] = 9;
     if (c3 % 2) radix[s++] = 3;
-    static const bool small_pow2 = getenv("M3D_FFT_BIG_RADIX") == nullptr;  // 4,4,4,2 beat 16,8 (VGPRs)
     // Z axis (short power-of-two transforms, k_z_conv<2>): as few radix-8 stages as bring the stage count
     // down to ceil(log2(n) / 3) - 128 = 8 * 4 * 4 has three barriers per transform instead of four
     // (measured 1.93 -> 1.71 ms); M3D_FFT_Z_RADIX4=1 keeps 4, 4, 4, 2.
     // X axis without register edge stages (in-LDS kernels): the same rule - 2048 = 8 * 8 * 8 * 4 is four LDS stages
     // per transform instead of the six of 4 * 4 * 4 * 4 * 4 * 2 (M3D_FFT_X_RADIX4=1 keeps the radix-4 lists)
     const bool x_eights = x_axis && !nine_last && getenv("M3D_FFT_X_RADIX4") == nullptr;
-    if ((x_eights || z_axis) && small_pow2 && getenv("M3D_FFT_Z_RADIX4") == nullptr) {
+    const bool y_eights = !x_axis && !z_axis && getenv("M3D_FFT_Y_RADIX4") == nullptr;  // run-time Y kernels alike
+    if ((x_eights || y_eights || (z_axis && getenv("M3D_FFT_Z_RADIX4") == nullptr)) && small_pow2) {
         const int best = (c2 + 2) / 3;
         int n8 = 0;
         while ((c2 - 3 * n8 + 1) / 2 + n8 > best) ++n8;
@@ -2035,6 +2062,7 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis
     if (c2 == 2) radix[s++] = 4;
     if (c2 == 1) radix[s++] = 2;
     if (nine_last) radix[s++] = 9;
+    if (eight_edges) radix[s++] = 8;
     *nstages = s;
     return s <= kMaxStages;
 }
@@ -2137,7 +2165,15 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->xreg = (knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 9 &&
                p->ax.radix[p->ax.nstages - 1] == 9 && p->xthreads == 256 && p->dual_threads == 256 &&
                p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 256 && Xp / 9 <= 256)
-                  ? 1 : 0;
+                  ? 9 : 0;
+    // edge radix 8 (factor_23 put an 8 first and last): S = Xp / 8 <= 256 edge items, S / 2 + 1 block pairs per packed
+    // row - 2 x 129 at Xp = 2048, so those workgroups take a fifth wave
+    if (!p->xreg && knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 8 &&
+        p->ax.radix[p->ax.nstages - 1] == 8 && p->rset_x == 2 && p->xthreads == 256 && p->dual_threads == 256 &&
+        p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && Xp % 64 == 0 && Xp / 8 <= 256) {
+        p->xreg = 8;
+        if (2 * (Xp / 16 + 1) > 256) p->xthreads = p->dual_threads = 320;
+    }
     p->ystatic = (knob("M3D_FFT_YSTATIC", 1) && Yp == 2187 && p->TW == 4 && p->lch == 7 && (p->ythreads == 768 || p->ythreads == 1024) &&
                   p->gy == 4 && p->ay.nstages == 4 && p->ay.radix[0] == 9 && p->ay.radix[1] == 9 &&
                   p->ay.radix[2] == 9 && p->ay.radix[3] == 3) ? 2187 : 0;
@@ -2153,7 +2189,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
                 p->ystatic = Yp;
                 p->ay.nstages = 4;
                 for (int i = 0; i < 4; ++i) p->ay.radix[i] = l[1 + i];
-                p->rset_y = 0;  // the run-time kernels that remain reachable (deep-pad mirror pass) need radix 8
+                p->rset_y = lean(p->ay);  // (the run-time mirror pass of a deep pad remains reachable: radix-8 build)
             }
     }
     // the static Y kernels spread (butterfly, column group) items over the threads: 972 (forward) / 486 (inverse) items
@@ -2345,6 +2381,8 @@ static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, 
         hipLaunchKernelGGL((k_y_pass_static<INV, 1296, 9, 9, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     else if (p->ystatic == 1152)
         hipLaunchKernelGGL((k_y_pass_static<INV, 1152, 9, 8, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->rset_y == 2)
+        hipLaunchKernelGGL((k_y_pass<INV, 2>), grid, block, p->lds_y, st, spec, g, p->ay);
     else if (p->rset_y)
         hipLaunchKernelGGL((k_y_pass<INV, 1>), grid, block, p->lds_y, st, spec, g, p->ay);
     else
@@ -2357,6 +2395,8 @@ static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spe
     const dim3 grid((unsigned)(g.in.nz * groups)), block(p->xthreads);
     if (p->xstatic) {
         hipLaunchKernelGGL((k_x_forward_reg<1, 2187>), grid, block, p->lds_x, st, src, spec, g, p->ax);
+    } else if (p->xreg == 8) {
+        hipLaunchKernelGGL((k_x_forward_reg<2, 0, 8>), grid, block, p->lds_x, st, src, spec, g, p->ax);
     } else if (p->xreg) {
         if (p->rset_x)
             hipLaunchKernelGGL(k_x_forward_reg<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
@@ -2396,6 +2436,8 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         else if (p->ystatic == 1296 && one_reflection) M3D_LAUNCH_YMS(1296, 9, 9, 4, 4, 1024);
         else if (p->ystatic == 1152 && one_reflection) M3D_LAUNCH_YMS(1152, 9, 8, 4, 4, 1024);
 #undef M3D_LAUNCH_YMS
+        else if (p->rset_y == 2)
+            hipLaunchKernelGGL(k_y_forward_mirror<2>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
         else if (p->rset_y)
             hipLaunchKernelGGL(k_y_forward_mirror<1>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
         else
@@ -2556,6 +2598,11 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, true, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, false, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+    } else if (p->xreg == 8) {
+        if (chain_forward)
+            hipLaunchKernelGGL((k_x_inverse_dual_reg<2, true, 0, 8>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+        else
+            hipLaunchKernelGGL((k_x_inverse_dual_reg<2, false, 0, 8>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     } else if (p->xreg) {
 #define M3D_LAUNCH_XD(RS, CH) \
     hipLaunchKernelGGL((k_x_inverse_dual_reg<RS, CH>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue)
@@ -2616,6 +2663,11 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
             hipLaunchKernelGGL((k_x_inverse_reg<1, 2, 2187>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
         else
             hipLaunchKernelGGL((k_x_inverse_reg<1, 0, 2187>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+    } else if (p->xreg == 8 && ep.kind != ConvEpilogue::kConsensus) {
+        if (ep.kind == ConvEpilogue::kUpdate)
+            hipLaunchKernelGGL((k_x_inverse_reg<2, 2, 0, false, 8>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+        else
+            hipLaunchKernelGGL((k_x_inverse_reg<2, 0, 0, false, 8>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
     } else if (p->xreg && ep.kind != ConvEpilogue::kConsensus) {
         if (p->rset_x) {
             if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XIR(1, 2);

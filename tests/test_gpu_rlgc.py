@@ -172,6 +172,32 @@ def test_solver_with_register_z_pass_matches_oracle(shape, psf_shape, padded):
     rl.clear_rlgc_caches(clear_memory_pool=True)
 
 
+@pytest.mark.parametrize("shape,padded", [((22, 70, 56), (32, 81, 64)),        # 64 = 8 * 8
+                                          ((22, 70, 120), (32, 81, 128)),      # 128 = 8 * 2 * 8
+                                          ((22, 40, 184), (32, 48, 192)),      # 192 = 8 * 3 * 8
+                                          ((22, 30, 568), (32, 48, 576)),      # 576 = 8 * 9 * 8
+                                          ((22, 28, 1144), (32, 36, 1152)),    # 1152 = 8 * 9 * 2 * 8
+                                          ((22, 27, 2040), (32, 36, 2048))])   # 2048 = 8 * 8 * 4 * 8: a fifth wave
+def test_solver_with_radix8_register_edges_matches_oracle(shape, padded):
+    """Padded X lengths 64 m without two radix-9 stages run the register-edge X passes with radix-8 edge stages (round
+    3): forward (mirrored and pruned inputs), plain / update inverse, the dual pass with its chained forward transform,
+    whole-line staging - all inside the solver, against the independent NumPy implementation, same Philox stream.  At
+    2048 a packed row has 129 block pairs, so two rows need a fifth wave per workgroup."""
+    rl = pkg("utils.rlgc")
+    img, psf = _phantom(shape, (9, 9, 9), (1.6, 1.5, 1.5), 90, seed=29)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, rinfo = rlgc_ref.rlgc(img, psf, rng="philox", return_info=True)
+    assert tuple(rinfo.padded_shape) == padded
+    out, info = rl.rlgc(img, psf, gpu_id=0, return_info=True, release_memory=False)
+    assert tuple(info.padded_shape) == padded
+    assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
+    np.testing.assert_allclose(info.kld_split1, rinfo.kld_split1, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=1e-4)
+    assert _rel_err(out, ref) < VOLUME_TOL
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+
+
 def test_rlgc_properties_at_medium_size():
     """Size-independent properties on a 32x256x256 volume (oracle too slow to be the checker)."""
     rl = pkg("utils.rlgc")
