@@ -951,9 +951,9 @@ __global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_reg(typenam
     const int groups = (y_hi - yg0 + g.RB - 1) / g.RB;
     const int z = g.out.z0 + blockIdx.x / groups, y0 = yg0 + (blockIdx.x % groups) * g.RB;
     const int nb = g.RB / 2, N = g.Xp, S = N / R, I = S / 2 + 1;
-    // static geometry (four rows per workgroup): neighbouring lanes take the two row pairs of one frequency pair, so a
-    // load instruction touches eight 128-byte lines (64 bytes of each) instead of sixteen (32 bytes of each)
-    const int pbi = NS ? (tid & 1) : (tid >= I ? 1 : 0), kp = NS ? (tid >> 1) : tid - pbi * I;
+    // four rows per workgroup: neighbouring lanes take the two row pairs of one frequency pair, so a load instruction
+    // touches eight 128-byte lines (64 bytes of each) instead of sixteen (32 bytes of each)
+    const int pbi = nb == 2 ? (tid & 1) : 0, kp = nb == 2 ? (tid >> 1) : tid;
     int u1 = 0, u2 = 0;
     XTwiddles xt;
     if constexpr (NS == 2187) xt = x_twiddles_2187(ax.tw, tid);
@@ -1156,9 +1156,9 @@ __global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_dual_reg(fl
     const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
     const int item = (g.xcdpair && b < (nblk & ~15)) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
     const int z = item / groups, y0 = (item % groups) * 2;
-    // static geometry: neighbouring lanes take the two rows of one frequency pair, so a load instruction covers 64
-    // contiguous bytes (both rows) of eight 128-byte lines instead of 32 bytes of sixteen
-    const int pbi = NS ? (tid & 1) : (tid >= I ? 1 : 0), kp = NS ? (tid >> 1) : tid - pbi * I;
+    // neighbouring lanes take the two rows of one frequency pair, so a load instruction covers 64 contiguous bytes
+    // (both rows) of eight 128-byte lines instead of 32 bytes of sixteen
+    const int pbi = tid & 1, kp = tid >> 1;
     const bool pair_live = tid < 2 * I;
     int pu1 = 0, pu2 = 0;
     int fu1 = 0, fu2 = 0;  // the chained forward transform's pairs: thread tid < I takes pair tid
