@@ -419,6 +419,14 @@ __device__ __forceinline__ void lds_stage(float2 *data, int n, int M, int estrid
             w[6] = cmul(w[2], w[4]);
             w[7] = cmul(w[3], w[4]);
             w[8] = cmul(w[4], w[4]);
+        } else if constexpr (R == 8 && M3D_TW_POWERS >= 1) {
+            w[1] = tw[j1];
+            w[2] = tw[2 * j1];
+            w[4] = tw[4 * j1];
+            w[3] = cmul(w[1], w[2]);
+            w[5] = cmul(w[1], w[4]);
+            w[6] = cmul(w[2], w[4]);
+            w[7] = cmul(w[3], w[4]);
         } else if constexpr ((R == 3 || R == 4) && M3D_TW_POWERS >= 1) {
             w[1] = tw[j1];
             w[2] = cmul(w[1], w[1]);

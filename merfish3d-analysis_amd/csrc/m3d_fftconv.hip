@@ -841,7 +841,7 @@ __device__ __forceinline__ void pair_offsets(const ConvGeo &g, int S, int kp, in
 }
 
 template <int RSET, int NS = 0, int R = 9>
-__global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_forward_reg(const float *__restrict__ src, float2 *__restrict__ spec,
+__global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_forward_reg(const float *__restrict__ src, float2 *__restrict__ spec,
                                                       ConvGeo g_, AxisPlan ax)
 {
     static_assert(R == 9 || (R == 8 && NS == 0), "edge radix 9, or 8 with run-time geometry");
@@ -936,7 +936,7 @@ struct SpecArg<true> {
     typedef float2 *type;
 };
 template <int RSET, int EPI, int NS = 0, bool CHAIN = false, int R = 9>
-__global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_reg(typename SpecArg<CHAIN>::type spec, float *__restrict__ dst,
+__global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_reg(typename SpecArg<CHAIN>::type spec, float *__restrict__ dst,
                                                       ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
 {
 #pragma clang fp contract(off)
@@ -1122,11 +1122,16 @@ __global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_reg(typenam
             smf[5 + (tid >> 6)] = dmax;
         }
         __syncthreads();
-        if (tid == 0) {  // (a fifth wave - radix-8 edges, S = 256 - holds no element: tid >= S)
+        if (tid == 0) {
             unsigned int *red = red_slot(ep.red);
-            const unsigned long long total = smu[0] + smu[1] + smu[2] + smu[3];
+            unsigned long long total = smu[0] + smu[1] + smu[2] + smu[3];
             mx = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
             dmax = fmaxf(fmaxf(smf[5], smf[6]), fmaxf(smf[7], smf[8]));
+            if (nt > 256) {  // a fifth wave (run-time geometry, S or the block pairs beyond 256)
+                total += smu[4];
+                mx = fmaxf(mx, smf[4]);
+                dmax = fmaxf(dmax, smf[9]);
+            }
             if (total) atomicAdd((unsigned long long *)red, total);
             atomicMax(&red[2], m3d::float_key(mx));
             atomicMax(&red[3], __float_as_uint(dmax));
@@ -1138,7 +1143,7 @@ __global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_reg(typenam
 // CHAIN, the product's X forward transform started from the same registers: the element the last inverse stage hands
 // thread t at x = t + S q is the element the first forward stage takes from it.
 template <int RSET, bool CHAIN, int NS = 0, int R = 9>
-__global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
+__global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
                                                            const float2 *__restrict__ spec2, ConvGeo g_, AxisPlan ax,
                                                            m3d::ConvEpilogue ep)
 {
@@ -1257,8 +1262,12 @@ __global__ __launch_bounds__(R == 8 ? 320 : 256, 4) void k_x_inverse_dual_reg(fl
     __syncthreads();
     if (tid == 0) {
         unsigned int *red = red_slot(ep.red);
-        mn = fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3]));  // (a fifth wave - radix-8 edges, S = 256 - holds no
-        mx = fmaxf(fmaxf(smf[5], smf[6]), fmaxf(smf[7], smf[8]));  //  element: tid >= S)
+        mn = fminf(fminf(smf[0], smf[1]), fminf(smf[2], smf[3]));
+        mx = fmaxf(fmaxf(smf[5], smf[6]), fmaxf(smf[7], smf[8]));
+        if (nt > 256) {  // a fifth wave (run-time geometry, S or the block pairs beyond 256)
+            mn = fminf(mn, smf[4]);
+            mx = fmaxf(mx, smf[9]);
+        }
         {
             atomicMin(&red[0], m3d::float_key(mn));
             atomicMax(&red[1], m3d::float_key(mx));
@@ -2136,7 +2145,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
         return v ? atoi(v) : dflt;
     };
     p->TW = knob("M3D_FFT_TW", 4);
-    while (p->TW > 1 && (size_t)Yp * p->TW * sizeof(float2) > 72 * 1024) p->TW /= 2;
+    while (p->TW > 1 && (size_t)Yp * p->TW * sizeof(float2) > (size_t)knob("M3D_FFT_YLDS_KB", 72) * 1024) p->TW /= 2;
     p->lds_y = (size_t)Yp * p->TW * sizeof(float2);
     // rows per X block: 4 real rows (2 packed) when they fit 40 KB, else 2
     p->RB = ((size_t)2 * Xp * sizeof(float2) <= 40 * 1024) ? knob("M3D_FFT_RB", 4) : 2;
@@ -2164,8 +2173,10 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->zthreads = std::max(p->P, knob("M3D_FFT_ZT", 128));
     p->xreg = (knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 9 &&
                p->ax.radix[p->ax.nstages - 1] == 9 && p->xthreads == 256 && p->dual_threads == 256 &&
-               p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 256 && Xp / 9 <= 256)
+               p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 320 && Xp / 9 <= 320)
                   ? 9 : 0;
+    // more than 256 edge items or block pairs (2592 = 9 * 288, the padded length of 2304-pixel sensors): a fifth wave
+    if (p->xreg == 9 && (Xp / 9 > 256 || 2 * (Xp / 18 + 1) > 256)) p->xthreads = p->dual_threads = 320;
     // edge radix 8 (factor_23 put an 8 first and last): S = Xp / 8 <= 256 edge items, S / 2 + 1 block pairs per packed
     // row - 2 x 129 at Xp = 2048, so those workgroups take a fifth wave
     if (!p->xreg && knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 8 &&
