@@ -1294,16 +1294,19 @@ __device__ __forceinline__ float load_count(const T *p, int64_t i)
     return (float)p[i];
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2, float2 *__restrict__ spec1, ConvGeo g_,
+// NS = 2187: compile-time geometry (the headline size).  NS = 0: run-time geometry for any length the register-edge
+// kernels take (edge radix R = 9 or 8, four rows per row group, tiles of four columns); same arithmetic.
+template <typename T, int NS = 2187, int R = 9, int RSET = 1>
+__global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(float2 *spec2, float2 *__restrict__ spec1, ConvGeo g_,
                                                               AxisPlan ax, m3d::SplitArgs sa)
 {
 #pragma clang fp contract(off)
+    static_assert(NS == 0 || (NS == 2187 && R == 9), "static geometry: 2187 = 9 * 9 * 3 * 9");
     extern __shared__ float2 lds_sp[];
-    __shared__ double smd[4][7];
-    constexpr int N = 2187, S = 243, I = 122;
-    const ConvGeo g = static_geo<2187>(g_);
-    const int tid = threadIdx.x;
+    __shared__ double smd[5][7];
+    const ConvGeo g = static_geo<NS>(g_);
+    const int N = NS ? NS : g.Xp, S = N / R, I = S / 2 + 1;
+    const int tid = threadIdx.x, nt = NS ? 256 : (int)blockDim.x;
     const int y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
     const int yg0 = (g.out.y0 / 4) * 4;  // the pairing of the other X passes (four rows per group, pairs inside)
     const int pairs = (y_hi - yg0 + 1) / 2;
@@ -1316,8 +1319,8 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
     const bool pair_live = tid < 2 * I;
     int pu1 = 0, pu2 = 0;
     if (pair_live) {
-        pu1 = ax.pos[kp] / 9;
-        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / 9;
+        pu1 = ax.pos[kp] / R;
+        pu2 = ax.pos[kp == 0 ? 0 : S - kp] / R;
     }
     const int64_t zterm = (int64_t)z * g.plane;
     if (tid < I) {
@@ -1342,12 +1345,12 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
                 if (!vb) Bv[i] = make_float2(0.f, 0.f);
             }
         }
-        inverse_pair_merge(lds_sp, S, N, kp, pu1, pu2, Av, Bv);
+        inverse_pair_merge<R>(lds_sp, S, N, kp, pu1, pu2, Av, Bv);
     }
     __syncthreads();
     // (table twiddles: this kernel is bound by its vector arithmetic - Philox, the threshold search, the split - and
     // holds 128 registers; the register twiddles of the other static X kernels cost it 6 %)
-    middle_inverse<1, 2187>(lds_sp, ax, 1, N, tid, 256, g.GX);
+    middle_inverse<RSET, NS>(lds_sp, ax, 1, N, tid, nt, g.GX);
     const float eps = 1e-4f;
     float sums[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // A, Bim, B1, B2, Tim, T1, T2 of this thread's 18 voxels
     if (tid < S) {
@@ -1361,20 +1364,20 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
         for (int r = 0; r < 2; ++r) {
             irows[r] = (plane0 + min(max(ya + r - g.out.y0, 0), g.out.ny - 1)) * g.out.nx;
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < R; ++q) {
                 const int xi = min(max(tid + S * q - g.out.x0, 0), g.out.nx - 1);
                 cnt[r][q] = load_count(image, irows[r] + xi);
                 inj[r][q] = sa.injected ? sa.injected[irows[r] + xi] : 0.0f;
             }
         }
         float2 w[9];
-        edge_twiddles(w, ax.tw, tid);  // (register limit: from the table, behind the image loads)
+        edge_twiddles<R>(w, ax.tw, tid);  // (register limit: from the table, behind the image loads)
         float2 v[9];  // (Hu of row ya, Hu of row ya + 1) at x = tid + S q
         const float2 *row = lds_sp + tid;
         v[0] = row[0];
 #pragma unroll
-        for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
-        dft9<true>(v);
+        for (int q = 1; q < R; ++q) v[q] = cmul_conj(row[S * q], w[q]);
+        edge_dft<R, true>(v);
         float2 p1[9], p2[9];  // (ratio1 of row ya, of row ya + 1), the same for ratio2; zero outside the core
 #pragma unroll
         for (int q = 0; q < 9; ++q) p1[q] = p2[q] = make_float2(0.f, 0.f);
@@ -1384,7 +1387,7 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
             if (!(r ? vb : va)) continue;
             const int64_t irow = irows[r];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) {
+            for (int q = 0; q < R; ++q) {
                 const int x = tid + S * q;
                 if (x < g.out.x0 || x >= x_hi) continue;
                 const float h = r ? v[q].y : v[q].x;
@@ -1423,16 +1426,16 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
         }
         {   // first forward stage of both packed ratio rows, into the slots this thread read (T) and their twins (P)
 #pragma clang fp contract(fast)
-            dft9<false>(p1);
+            edge_dft<R, false>(p1);
             float2 *o1 = lds_sp + tid;
             o1[0] = p1[0];
 #pragma unroll
-            for (int q = 1; q < 9; ++q) o1[S * q] = cmul(p1[q], w[q]);
-            dft9<false>(p2);
+            for (int q = 1; q < R; ++q) o1[S * q] = cmul(p1[q], w[q]);
+            edge_dft<R, false>(p2);
             float2 *o2 = lds_sp + N + tid;
             o2[0] = p2[0];
 #pragma unroll
-            for (int q = 1; q < 9; ++q) o2[S * q] = cmul(p2[q], w[q]);
+            for (int q = 1; q < R; ++q) o2[S * q] = cmul(p2[q], w[q]);
         }
     }
     // the seven sums: wave shuffles, then four values per sum through LDS; they ride the barrier the transforms need
@@ -1450,17 +1453,20 @@ __global__ __launch_bounds__(256, 4) void k_x_inverse_split_chain(float2 *spec2,
         const double ln2 = 0.69314718055994530942;
         double t[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) t[k] = ((smd[0][k] + smd[1][k]) + smd[2][k]) + smd[3][k];
+        for (int k = 0; k < 7; ++k) {
+            t[k] = ((smd[0][k] + smd[1][k]) + smd[2][k]) + smd[3][k];
+            if (nt > 256) t[k] += smd[4][k];  // a fifth wave (run-time geometry, more than 256 edge items or pairs)
+        }
         m3d::SplitPartial out = {t[0], t[1], t[2], t[3], t[4] * ln2, t[5] * ln2, t[6] * ln2};
         sa.partial[blockIdx.x] = out;
     }
     {
 #pragma clang fp contract(fast)
-        middle_forward<1, 2187>(lds_sp, ax, 2, N, tid, 256, g.GX);
+        middle_forward<RSET, NS>(lds_sp, ax, 2, N, tid, nt, g.GX);
         if (pair_live) {
             float2 c1[9], c2[9];
-            forward_pair_load(lds_sp + pbi * N, pu1, pu2, c1, c2);
-            forward_pair_emit<false>(c1, c2, g, S, kp, pbi ? spec2 : spec1, zterm, ya, va, vb);
+            forward_pair_load<R>(lds_sp + pbi * N, pu1, pu2, c1, c2);
+            forward_pair_emit<false, R>(c1, c2, g, S, kp, pbi ? spec2 : spec1, zterm, ya, va, vb);
         }
     }
 }
@@ -2563,7 +2569,17 @@ int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *s
     return M3D_OK;
 }
 
-bool fftconv_split_chain_supported(const FftConvPlan *p) { return p && p->xstatic && p->TW == 4 && p->RB == 4; }
+// Static geometry (2187).  The kernel also has run-time geometry builds for every length the register-edge kernels take
+// with four rows per group and tiles of four (M3D_FFT_SPLIT_CHAIN_RT=1): parity green, but measured no faster than the
+// separate kernels there (2048: 18.2 against 17.6 ms per iteration - a fifth wave at 121 registers leaves three
+// workgroups per CU; 1728 / 1296 / 1152: -1 to +1 %; profiles/r03_sizes.txt), so they stay off by default.
+bool fftconv_split_chain_supported(const FftConvPlan *p)
+{
+    if (!p || p->TW != 4 || p->RB != 4) return false;
+    if (p->xstatic) return true;
+    const bool rt = getenv("M3D_FFT_SPLIT_CHAIN_RT") && atoi(getenv("M3D_FFT_SPLIT_CHAIN_RT")) == 1;
+    return rt && ((p->xreg == 9 && p->rset_x == 1) || (p->xreg == 8 && p->rset_x == 2));
+}
 
 int64_t fftconv_split_chain_blocks(const FftConvPlan *p, const ConvBox *core)
 {
@@ -2581,12 +2597,21 @@ int fftconv_split_chain(const FftConvPlan *p, float2 *spec_hu, float2 *spec_r1, 
         !args->partial || !args->tables.thr)
         return M3D_ERR_INVALID_ARG;
     const ConvGeo g = geo_of(p, nullptr, core);
-    const dim3 grid((unsigned)fftconv_split_chain_blocks(p, core)), block(256);
+    const dim3 grid((unsigned)fftconv_split_chain_blocks(p, core)), block(p->xstatic ? 256 : p->dual_threads);
     const size_t lds = (size_t)2 * p->Xp * sizeof(float2);
-    if (args->image_is_u16)
-        hipLaunchKernelGGL(k_x_inverse_split_chain<uint16_t>, grid, block, lds, st, spec_hu, spec_r1, g, p->ax, *args);
-    else
-        hipLaunchKernelGGL(k_x_inverse_split_chain<float>, grid, block, lds, st, spec_hu, spec_r1, g, p->ax, *args);
+#define M3D_LAUNCH_SC(T, NS, R, RS) \
+    hipLaunchKernelGGL((k_x_inverse_split_chain<T, NS, R, RS>), grid, block, lds, st, spec_hu, spec_r1, g, p->ax, *args)
+    if (p->xstatic) {
+        if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 2187, 9, 1);
+        else M3D_LAUNCH_SC(float, 2187, 9, 1);
+    } else if (p->xreg == 8) {
+        if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 0, 8, 2);
+        else M3D_LAUNCH_SC(float, 0, 8, 2);
+    } else {
+        if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 0, 9, 1);
+        else M3D_LAUNCH_SC(float, 0, 9, 1);
+    }
+#undef M3D_LAUNCH_SC
     if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();
     return M3D_OK;
