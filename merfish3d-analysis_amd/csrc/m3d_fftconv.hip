@@ -1352,6 +1352,7 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
     // holds 128 registers; the register twiddles of the other static X kernels cost it 6 %)
     middle_inverse<RSET, NS>(lds_sp, ax, 1, N, tid, nt, g.GX);
     const float eps = 1e-4f;
+    const uint32_t iteration = sa.iteration_dev ? *sa.iteration_dev : sa.iteration;
     float sums[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // A, Bim, B1, B2, Tim, T1, T2 of this thread's 18 voxels
     if (tid < S) {
         const T *image = (const T *)sa.image;
@@ -1398,7 +1399,7 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
                 } else {
                     const float vt = val > 0.0f ? val : 0.0f;
                     const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);  // astype(int64) truncation, rlgc.py:619
-                    s1 = (float)m3d::binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + (x - g.out.x0)), sa.iteration,
+                    s1 = (float)m3d::binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + (x - g.out.x0)), iteration,
                                                                       sa.seed, sa.tables);
                 }
                 const float s2 = val - s1;

@@ -35,6 +35,35 @@ def _hw4_codebook(n_bits=22, n_codes=140, seed=0):
     return bits
 
 
+def test_rlgc_at_the_first_fallback_crop_equals_the_in_lds_route(monkeypatch):
+    """64 x 1920 x 1920 (the first OOM-fallback crop of a 2048 tile; FFT volume 128 x 2048 x 2048) at full size: the
+    round-3 kernels of that geometry - static Y passes with the radix list 8 8 8 4, register-edge X passes with radix-8
+    edge stages and a fifth wave per workgroup (2048 = 8 8 4 8: 129 block pairs per packed row) - against the in-LDS X
+    kernels and the run-time Y kernel (M3D_FFT_XREG8=0, M3D_FFT_YSTATIC=0), which the oracle comparisons at small sizes
+    pin: grids of 262 144 workgroups, 64-bit plane offsets, the fused consensus / update tails."""
+    rl = pkg("utils.rlgc")
+    g = torch.Generator(device=DEV).manual_seed(5)
+    shape = (64, 1920, 1920)
+    img = torch.poisson(torch.rand(shape, device=DEV, generator=g) * 300 + 80, generator=g).to(torch.uint16)
+    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (64, 51, 51)], indexing="ij")
+    psf = torch.exp(-0.5 * ((zz / 3.0) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2)).float()
+    out = {}
+    for new in ("1", "0"):
+        rl.clear_rlgc_caches(clear_memory_pool=True)        # the switches are read when a plan is created
+        monkeypatch.setenv("M3D_FFT_XREG8", new)
+        monkeypatch.setenv("M3D_FFT_YSTATIC", new)
+        o, info = rl.rlgc_device(img, psf, rng_seed=7, max_iterations=3)
+        out[new] = (o.clone(), info)
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+    a, b = out["1"], out["0"]
+    assert a[1].padded_shape == (128, 2048, 2048) and a[1].fused_engine and a[1].iterations == b[1].iterations == 3
+    np.testing.assert_allclose(a[1].kld_split1[:3], b[1].kld_split1[:3], rtol=1e-5)
+    np.testing.assert_allclose(a[1].kld_image[:3], b[1].kld_image[:3], rtol=1e-5)
+    rel = float((a[0] - b[0]).abs().max() / b[0].abs().max())
+    assert rel < 2e-5, rel
+    assert abs(float(a[0].mean()) / float(img.float().mean()) - 2.0) < 0.02
+
+
 def test_rlgc_full_size_is_deterministic_and_pruning_invariant(monkeypatch):
     rl = pkg("utils.rlgc")
     g = torch.Generator(device=DEV).manual_seed(3)
