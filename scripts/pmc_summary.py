@@ -77,10 +77,12 @@ def main():
         "rlgc_iteration_hbm_bytes": per_iteration,
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/gpu_probe_rlgc.py 64 2048 2048 2",
         "correction": "bytes = 2 * FETCH_SIZE[KiB] * 1024 + WRITE_SIZE[KiB] * 1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)",
-        "calibration": ("k_floor / k_crop / k_image_sum (4- and 2-byte-per-lane streaming reads of known size) confirm the x2; "
-                        "the OTF-only k_z_conv dispatch (reads exactly one spectrum = 1.0 volume) shows 0.752 raw, i.e. the x2 "
-                        "over-corrects the 8-byte-per-lane 128-B-segment pattern by 1.5x, and a plain k_x_inverse (reads one "
-                        "spectrum) shows 0.877 raw: treat the corrected figures of those two kernels as upper bounds"),
+        "calibration": ("k_floor / k_crop / k_image_sum / k_otf_abs2 (streaming reads of known size) confirm the x2 to three digits, "
+                        "and the L2's own request counters (TCC_EA0_RDREQ x 128 B, TCC_EA0_WRREQ x 64 B; round 3, "
+                        "profiles/r03_l2_fabric.txt) give the same bytes: the corrected figures are what crosses the L2's "
+                        "memory side.  Kernels that show more than their algorithmic bytes (the X inverse passes that read "
+                        "half lines, some Z passes) really request those lines twice; the repeats are served by the Infinity "
+                        "Cache, which sits behind these counters (round 1 had read the excess as a counter artefact)"),
         "padded_volume_bytes": vol,
         "fft_conv_launches": n_conv,
         "fft_conv_hbm_bytes_per_launch": total / max(n_conv, 1),
