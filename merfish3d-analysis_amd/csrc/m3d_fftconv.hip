@@ -71,7 +71,6 @@ struct FftConvPlan {
     int xcdpair;
     int ystatic;  // the Y pass runs its static-geometry build
     int xstatic;  // the register-edge X passes run their static-geometry builds (NS = 2187)
-    int dualseq;  // static geometry: the chained dual X pass runs k_x_inverse_dual_seq (one LDS row, eight workgroups per CU)
 };
 
 }  // namespace m3d
@@ -1285,232 +1284,6 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_dual_reg(float2
     }
 }
 
-// ---------------------------------------------------------------- dual X inverse pass, one LDS row, eight workgroups per CU
-// The chained dual pass of the static geometry with the two rows of a pair transformed ONE AFTER THE OTHER through a
-// single 17.5-KB LDS row, one 9-point butterfly's operands per thread: 256 threads, <= 64 registers, so that a CU holds
-// eight workgroups (32 waves from eight independent barrier domains) instead of four.  (Twice the waves inside the
-// same four workgroups - 512 threads, commit 622b42a - was 19 % slower: the waves of one workgroup are always in the
-// same phase and compete for the same unit.)  Same operations on the same values in the same order as
-// k_x_inverse_dual_reg<1, true, 2187>.
-#ifndef M3D_DUALSEQ_WAVES
-#define M3D_DUALSEQ_WAVES 6  // waves per SIMD the kernel is compiled for (80 registers: no scratch; 8 -> 64 registers, 16 spilled)
-#endif
-__device__ __forceinline__ float2 lane_xor1(float2 v)  // the value of lane t ^ 1 (quad_perm [1, 0, 3, 2])
-{
-    const int x = __builtin_amdgcn_mov_dpp(__float_as_int(v.x), 0xB1, 0xF, 0xF, true);
-    const int y = __builtin_amdgcn_mov_dpp(__float_as_int(v.y), 0xB1, 0xF, 0xF, true);
-    return make_float2(__int_as_float(x), __int_as_float(y));
-}
-template <bool INV>
-__device__ __forceinline__ void seq_stage27(float2 *row, const float2 *__restrict__ tw, int tid)
-{
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {  // 729 radix-3 butterflies of block size 27, the block along the lanes (x_stage27)
-        const int t = tid + 256 * k;
-        if (t >= 729) break;
-        const int j = t / 81, blk = t - j * 81;
-        float2 *p = row + blk * 27 + j;
-        const float2 w1 = tw[81 * j], w2 = cmul(w1, w1);
-        float2 u0 = p[0], u1 = p[9], u2 = p[18];
-        if (INV) {
-            u1 = cmul_conj(u1, w1);
-            u2 = cmul_conj(u2, w2);
-            dft3<true>(u0, u1, u2);
-        } else {
-            dft3<false>(u0, u1, u2);
-            u1 = cmul(u1, w1);
-            u2 = cmul(u2, w2);
-        }
-        p[0] = u0;
-        p[9] = u1;
-        p[18] = u2;
-    }
-}
-template <bool INV>
-__device__ __forceinline__ void seq_stage243(float2 *row, const float2 *__restrict__ tw, int tid)
-{
-    if (tid >= 243) return;  // 243 radix-9 butterflies of block size 243 (x_stage243)
-    const int blk = tid / 27, j = tid - blk * 27;
-    float2 w[9];
-    powers_124(w, tw[9 * j], tw[18 * j], tw[36 * j]);
-    float2 *p = row + blk * 243 + j;
-    float2 v[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) v[q] = p[q * 27];
-    if (INV) {
-#pragma unroll
-        for (int q = 1; q < 9; ++q) v[q] = cmul_conj(v[q], w[q]);
-        dft9<true>(v);
-    } else {
-        dft9<false>(v);
-#pragma unroll
-        for (int q = 1; q < 9; ++q) v[q] = cmul(v[q], w[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) p[q * 27] = v[q];
-}
-
-__global__ __launch_bounds__(256, M3D_DUALSEQ_WAVES) void k_x_inverse_dual_seq(float2 *__restrict__ spec1, const float2 *__restrict__ spec2,
-                                                           ConvGeo g_, AxisPlan ax, m3d::ConvEpilogue ep)
-{
-#pragma clang fp contract(off)
-    extern __shared__ float2 lds_sq[];
-    __shared__ float smf_sq[8];
-    constexpr int N = 2187, S = 243, I = 122;
-    const ConvGeo g = static_geo<2187>(g_);
-    const int tid = threadIdx.x;
-    const int groups = (N + 1) / 2;
-    const int nblk = (int)gridDim.x, b = (int)blockIdx.x;
-    const int item = (g.xcdpair && b < (nblk & ~15)) ? ((b & ~15) | ((b & 7) << 1) | ((b >> 3) & 1)) : b;
-    const int z = item / groups, y0 = (item % groups) * 2;
-    const bool row1 = y0 + 1 < N;
-    const int64_t zterm = (int64_t)z * g.plane;
-    const float2 *__restrict__ tw = ax.tw;
-    const int half = tid & 1, kp = tid >> 1;  // merge / emit items: lane (pair k', block), 244 of them
-    const int kb = half ? (kp == 0 ? 0 : S - kp) : kp;
-    const bool self = kp == 0;
-    int pu = 0;
-    if (kp < I) pu = ax.pos[min(kb, S - 1)] / 9;
-    float mn = INFINITY, mx = -INFINITY;
-    float prod0[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) prod0[q] = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (kp < I) {  // Hermitian merge + first inverse stage of row y0 + r (uniform over a lane pair)
-            int rows_c;
-            const int rb = row_base(g, min(y0 + r, N - 1), rows_c);
-            const int64_t rbase = zterm + rb;
-            float2 Av[5], Bv[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {  // (block S - k' holds four stored frequencies: its fifth load is a stand-in)
-                const int off = tile_term(g, min(kb + S * d, g.Xc - 1), rows_c);
-                Av[d] = spec1[rbase + off];
-                Bv[d] = spec2[rbase + off];
-            }
-            float2 c[9], mir[5], got[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) {
-                c[d] = add_i(Av[d], Bv[d]);
-                mir[d] = conj_add_i_conj(Av[d], Bv[d]);
-            }
-#pragma unroll
-            for (int d = 0; d < 5; ++d) got[d] = lane_xor1(mir[d]);
-            if (half) c[4] = got[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const float2 own = mir[d + 1], oth = got[d];  // slot 8 - d
-                c[8 - d] = make_float2(self ? own.x : oth.x, self ? own.y : oth.y);
-            }
-            if (!(half && self)) {
-                dft9<true>(c);
-                float2 *row = lds_sq + 9 * pu;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) row[q] = c[q];
-            }
-        }
-        __syncthreads();
-        seq_stage27<true>(lds_sq, tw, tid);
-        __syncthreads();
-        seq_stage243<true>(lds_sq, tw, tid);
-        __syncthreads();
-        if (tid < S) {  // last inverse stage + consensus arithmetic of row y0 + r
-            float2 v[9];
-            {
-                float2 w[9];
-                powers_124(w, tw[tid], tw[2 * tid], tw[4 * tid]);
-                const float2 *row = lds_sq + tid;
-                v[0] = row[0];
-#pragma unroll
-                for (int q = 1; q < 9; ++q) v[q] = cmul_conj(row[S * q], w[q]);
-            }
-            dft9<true>(v);
-            const bool live = r == 0 || row1;
-            const int y = y0 + (live ? r : 0);
-            const int64_t rr = ((int64_t)z * N + y) * N;
-            const bool yc = live && z >= ep.core.z0 && z < ep.core.z0 + ep.core.nz && y >= ep.core.y0 &&
-                            y < ep.core.y0 + ep.core.ny;
-            float un[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) un[q] = ep.b[rr + tid + S * q];
-            float2 pk[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int n = tid + S * q;
-                const float h1 = v[q].x * un[q], h2 = v[q].y * un[q];  // un = 1 / update_norm
-                const float prod = (h1 - 1.0f) * (h2 - 1.0f);
-                if (live) {
-                    const float hs = h1 + h2;
-                    mn = fminf(mn, hs);
-                    mx = fmaxf(mx, hs);
-                    if (yc && n >= ep.core.x0 && n < ep.core.x0 + ep.core.nx) ep.o2[rr + n] = hs;
-                }
-                if (r == 0) prod0[q] = prod;
-                else pk[q] = make_float2(prod0[q], row1 ? prod : 0.0f);
-            }
-            if (r == 1) {
-                // first forward stage of the packed product rows, into the slots this thread has just read
-#pragma clang fp contract(fast)
-                float2 w[9];
-                powers_124(w, tw[tid], tw[2 * tid], tw[4 * tid]);
-                dft9<false>(pk);
-                float2 *orow = lds_sq + tid;
-                orow[0] = pk[0];
-#pragma unroll
-                for (int q = 1; q < 9; ++q) orow[S * q] = cmul(pk[q], w[q]);
-            }
-        }
-        if (r == 1) {  // per-wave extrema ride the barrier the chained forward needs anyway
-            mn = m3d::wave_min(mn);
-            mx = m3d::wave_max(mx);
-            if ((tid & 63) == 0) {
-                smf_sq[tid >> 6] = mn;
-                smf_sq[4 + (tid >> 6)] = mx;
-            }
-        }
-        __syncthreads();  // r = 0: every thread has read the row before the next merge overwrites it
-    }
-    if (tid == 0) {
-        unsigned int *red = red_slot(ep.red);
-        mn = fminf(fminf(smf_sq[0], smf_sq[1]), fminf(smf_sq[2], smf_sq[3]));
-        mx = fmaxf(fmaxf(smf_sq[4], smf_sq[5]), fmaxf(smf_sq[6], smf_sq[7]));
-        atomicMin(&red[0], m3d::float_key(mn));
-        atomicMax(&red[1], m3d::float_key(mx));
-    }
-    {
-#pragma clang fp contract(fast)
-        seq_stage243<false>(lds_sq, tw, tid);
-        __syncthreads();
-        seq_stage27<false>(lds_sq, tw, tid);
-        __syncthreads();
-        if (kp < I) {  // last forward stage + Hermitian split: one block's butterfly per lane, mirror partners by DPP
-            float2 c[9];
-            const float2 *row = lds_sq + 9 * pu;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) c[q] = row[q];
-            dft9<false>(c);
-            float2 got[5];
-#pragma unroll
-            for (int d = 0; d < 5; ++d) got[d] = lane_xor1(c[8 - d]);
-            if (!(half && self)) {
-                int rows_c;
-                const int rbase = row_base(g, y0, rows_c);
-                const float2 hf = make_float2(0.5f, 0.5f);
-#pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    if (d == 4 && half) break;  // block S - k' holds four stored frequencies
-                    const float2 own = c[(9 - d) % 9];  // block 0: the mirror of S d is S (9 - d)
-                    const float2 m = make_float2(self ? own.x : got[d].x, self ? own.y : got[d].y);
-                    const float2 A = add_conj(c[d], m) * hf, B = split_odd(c[d], m) * hf;
-                    const int in_plane = rbase + tile_term(g, kb + S * d, rows_c);
-                    spec1[zterm + in_plane] = A;
-                    if (row1) spec1[zterm + in_plane + 4] = B;
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- X inverse of Hu + split + two X forward transforms
 // One row pair (y, y + 1) of one core plane per workgroup; static geometry (2187 = 9 * 9 * 3 * 9) only.  LDS: two
 // rows of N complex values - T carries the packed inverse transform of the pair and then ratio1's packed forward
@@ -2443,7 +2216,6 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
                   p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&
                   p->ax.radix[2] == 3) ? 1 : 0;
-    p->dualseq = (p->xstatic && knob("M3D_FFT_DUALSEQ", 1)) ? 1 : 0;
     if (p->lds_y > 150 * 1024 || p->lds_x > 150 * 1024 || p->lds_z > 150 * 1024) {
         delete p;
         return M3D_ERR_UNSUPPORTED;
@@ -2859,10 +2631,7 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
     const size_t lds = (size_t)nb * p->Xp * sizeof(float2);
     const dim3 grid((unsigned)(p->Zp * ((p->Yp + nb - 1) / nb))), block(p->dual_threads);
     if (p->xstatic) {
-        if (chain_forward && p->dualseq)
-            hipLaunchKernelGGL(k_x_inverse_dual_seq, grid, dim3(256), (size_t)p->Xp * sizeof(float2), st, spec1, spec2, g, p->ax,
-                               *epilogue);
-        else if (chain_forward)
+        if (chain_forward)
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, true, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
             hipLaunchKernelGGL((k_x_inverse_dual_reg<1, false, 2187>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);

@@ -402,37 +402,6 @@ def test_graph_replayed_loop_equals_plain_launches(monkeypatch, shape, psf_shape
     rl.clear_rlgc_caches(clear_memory_pool=True)
 
 
-def test_sequential_row_dual_pass_equals_the_two_row_one(monkeypatch):
-    """The chained dual X inverse pass of lateral size 2187 has two builds: both rows of a pair side by side in two LDS
-    rows (k_x_inverse_dual_reg) and one after the other through a single row with a butterfly's operands per thread
-    (k_x_inverse_dual_seq, M3D_FFT_DUALSEQ).  Same operations on the same values in the same order: same iterations,
-    same traces, volumes equal to the last bit or to a rounding of one transform.  The last (single) row of the 2187
-    and the planes outside the core are part of every solve at this size."""
-    rl = pkg("utils.rlgc")
-    gen = torch.Generator(device=DEV).manual_seed(23)
-    shape = (22, 2140, 2140)
-    img = torch.poisson(torch.rand(shape, device=DEV, generator=gen) * 200 + 50, generator=gen).to(torch.uint16)
-    img[7, 1500:1530, 40:90] = 30000
-    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (9, 47, 47)], indexing="ij")
-    psf = torch.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.8) ** 2 + (xx / 1.8) ** 2)).float()
-    out = {}
-    for seq in ("1", "0"):
-        rl.clear_rlgc_caches(clear_memory_pool=True)        # the switch is read when a plan is created
-        monkeypatch.setenv("M3D_FFT_DUALSEQ", seq)
-        o, info = rl.rlgc_device(img, psf, max_iterations=5, rng_seed=9)
-        out[seq] = (o.clone(), info)
-    rl.clear_rlgc_caches(clear_memory_pool=True)
-    a, b = out["1"], out["0"]
-    assert tuple(a[1].padded_shape) == (32, 2187, 2187)
-    assert (a[1].iterations, a[1].stop_reason) == (b[1].iterations, b[1].stop_reason)
-    np.testing.assert_allclose(a[1].kld_split1, b[1].kld_split1, rtol=1e-6, atol=1e-9)
-    np.testing.assert_allclose(a[1].update_min, b[1].update_min, rtol=1e-6)
-    np.testing.assert_allclose(a[1].update_max, b[1].update_max, rtol=1e-6)
-    err = float((a[0] - b[0]).abs().max() / b[0].abs().max())
-    print(f"sequential-row vs two-row dual pass: max rel diff {err:.3e}, bit-equal {torch.equal(a[0], b[0])}")
-    assert err < 2e-6
-
-
 def test_static_geometry_kernels_equal_the_generic_ones(monkeypatch):
     """Lateral size 2187 runs kernels compiled for that geometry (register-resident twiddles, unrolled middle stages,
     static Y stages, chained tails); M3D_FFT_XSTATIC=0 / M3D_FFT_YSTATIC=0 send the same solve through the run-time
