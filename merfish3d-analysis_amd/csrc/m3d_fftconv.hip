@@ -680,6 +680,31 @@ __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, 
         __syncthreads();
         return;
     }
+    // The common lengths with radix-8 edge stages get their middle stages with literal geometry (block sizes, strides,
+    // trip counts and the division of the item index fold): 2048 = 8 [8 4] 8 at 320 threads, 1728 = 8 [9 3] 8 and
+    // 1152 = 8 [9 2] 8 at 256.  Same stages in the same order as the loop below.
+    if constexpr (NS == 0 && (RSET == 1 || RSET == 2)) {
+#define M3D_MID_F(NN, R1, M1, R2, M2, NTH)                                        \
+    if (N == NN && nt == NTH && (nb == 1 || nb == 2)) {                           \
+        if (nb == 2) lds_stage<R1, false>(lds, NN, M1, 1, 2, NN, ax.tw, tid, NTH, 4); \
+        else lds_stage<R1, false>(lds, NN, M1, 1, 1, NN, ax.tw, tid, NTH, 4);      \
+        __syncthreads();                                                          \
+        if (nb == 2) lds_stage<R2, false>(lds, NN, M2, 1, 2, NN, ax.tw, tid, NTH, 4); \
+        else lds_stage<R2, false>(lds, NN, M2, 1, 1, NN, ax.tw, tid, NTH, 4);      \
+        __syncthreads();                                                          \
+        return;                                                                   \
+    }
+        if constexpr (RSET == 2) {
+            if (gmax == 4) {
+                M3D_MID_F(2048, 8, 256, 4, 32, 320)
+                M3D_MID_F(1728, 9, 216, 3, 24, 256)
+                M3D_MID_F(1152, 9, 144, 2, 16, 256)
+            }
+        } else if (gmax == 4) {
+            M3D_MID_F(1296, 4, 144, 4, 36, 256)  // 9 [4 4] 9
+        }
+#undef M3D_MID_F
+    }
     int M = N / ax.radix[0];
     for (int s = 1; s < ax.nstages - 1; ++s) {
         const int r = ax.radix[s];
@@ -697,6 +722,28 @@ __device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, 
         lds_stage<9, true>(lds, 2187, 243, 1, nb, 2187, ax.tw, tid, 256, 4);
         __syncthreads();
         return;
+    }
+    if constexpr (NS == 0 && (RSET == 1 || RSET == 2)) {  // (see middle_forward)
+#define M3D_MID_I(NN, R1, M1, R2, M2, NTH)                                       \
+    if (N == NN && nt == NTH && (nb == 1 || nb == 2)) {                          \
+        if (nb == 2) lds_stage<R2, true>(lds, NN, M2, 1, 2, NN, ax.tw, tid, NTH, 4); \
+        else lds_stage<R2, true>(lds, NN, M2, 1, 1, NN, ax.tw, tid, NTH, 4);      \
+        __syncthreads();                                                         \
+        if (nb == 2) lds_stage<R1, true>(lds, NN, M1, 1, 2, NN, ax.tw, tid, NTH, 4); \
+        else lds_stage<R1, true>(lds, NN, M1, 1, 1, NN, ax.tw, tid, NTH, 4);      \
+        __syncthreads();                                                         \
+        return;                                                                  \
+    }
+        if constexpr (RSET == 2) {
+            if (gmax == 4) {
+                M3D_MID_I(2048, 8, 256, 4, 32, 320)
+                M3D_MID_I(1728, 9, 216, 3, 24, 256)
+                M3D_MID_I(1152, 9, 144, 2, 16, 256)
+            }
+        } else if (gmax == 4) {
+            M3D_MID_I(1296, 4, 144, 4, 36, 256)
+        }
+#undef M3D_MID_I
     }
     int M = ax.radix[0];  // (= the last stage's radix: the edge stages share theirs)
     for (int s = ax.nstages - 2; s >= 1; --s) {
@@ -1143,7 +1190,7 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_reg(typename Sp
 // CHAIN, the product's X forward transform started from the same registers: the element the last inverse stage hands
 // thread t at x = t + S q is the element the first forward stage takes from it.
 template <int RSET, bool CHAIN, int NS = 0, int R = 9>
-__global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
+__global__ __launch_bounds__(NS ? 256 : 320, (NS == 0 && R == 8) ? 5 : 4) void k_x_inverse_dual_reg(float2 *__restrict__ spec1,
                                                            const float2 *__restrict__ spec2, ConvGeo g_, AxisPlan ax,
                                                            m3d::ConvEpilogue ep)
 {
