@@ -697,6 +697,7 @@ __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, 
         if constexpr (RSET == 2) {
             if (gmax == 4) {
                 M3D_MID_F(2048, 8, 256, 4, 32, 320)
+                M3D_MID_F(2592, 8, 288, 4, 36, 320)  // 9 [8 4] 9
                 M3D_MID_F(1728, 9, 216, 3, 24, 256)
                 M3D_MID_F(1152, 9, 144, 2, 16, 256)
             }
@@ -737,6 +738,7 @@ __device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, 
         if constexpr (RSET == 2) {
             if (gmax == 4) {
                 M3D_MID_I(2048, 8, 256, 4, 32, 320)
+                M3D_MID_I(2592, 8, 288, 4, 36, 320)
                 M3D_MID_I(1728, 9, 216, 3, 24, 256)
                 M3D_MID_I(1152, 9, 144, 2, 16, 256)
             }
@@ -2101,7 +2103,8 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis
     // (measured 1.93 -> 1.71 ms); M3D_FFT_Z_RADIX4=1 keeps 4, 4, 4, 2.
     // X axis without register edge stages (in-LDS kernels): the same rule - 2048 = 8 * 8 * 8 * 4 is four LDS stages
     // per transform instead of the six of 4 * 4 * 4 * 4 * 4 * 2 (M3D_FFT_X_RADIX4=1 keeps the radix-4 lists)
-    const bool x_eights = x_axis && !nine_last && getenv("M3D_FFT_X_RADIX4") == nullptr;
+    const bool x_eights = x_axis && getenv("M3D_FFT_X_RADIX4") == nullptr;  // (also between two radix-9 edge stages:
+                                                                             //  2592 = 9 8 4 9 instead of 9 4 4 2 9)
     const bool y_eights = !x_axis && !z_axis && getenv("M3D_FFT_Y_RADIX4") == nullptr;  // run-time Y kernels alike
     if ((x_eights || y_eights || (z_axis && getenv("M3D_FFT_Z_RADIX4") == nullptr)) && small_pow2) {
         const int best = (c2 + 2) / 3;
@@ -2462,6 +2465,8 @@ static void launch_x_forward(const FftConvPlan *p, const float *src, float2 *spe
         hipLaunchKernelGGL((k_x_forward_reg<1, 2187>), grid, block, p->lds_x, st, src, spec, g, p->ax);
     } else if (p->xreg == 8) {
         hipLaunchKernelGGL((k_x_forward_reg<2, 0, 8>), grid, block, p->lds_x, st, src, spec, g, p->ax);
+    } else if (p->xreg && p->rset_x == 2) {
+        hipLaunchKernelGGL((k_x_forward_reg<2, 0, 9>), grid, block, p->lds_x, st, src, spec, g, p->ax);
     } else if (p->xreg) {
         if (p->rset_x)
             hipLaunchKernelGGL(k_x_forward_reg<1>, grid, block, p->lds_x, st, src, spec, g, p->ax);
@@ -2687,6 +2692,11 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
             hipLaunchKernelGGL((k_x_inverse_dual_reg<2, true, 0, 8>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
         else
             hipLaunchKernelGGL((k_x_inverse_dual_reg<2, false, 0, 8>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+    } else if (p->xreg && p->rset_x == 2) {
+        if (chain_forward)
+            hipLaunchKernelGGL((k_x_inverse_dual_reg<2, true, 0, 9>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
+        else
+            hipLaunchKernelGGL((k_x_inverse_dual_reg<2, false, 0, 9>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue);
     } else if (p->xreg) {
 #define M3D_LAUNCH_XD(RS, CH) \
     hipLaunchKernelGGL((k_x_inverse_dual_reg<RS, CH>), grid, block, lds, st, spec1, spec2, g, p->ax, *epilogue)
@@ -2752,6 +2762,11 @@ int fftconv_conv(const FftConvPlan *p, const float *src, const float2 *otf, int 
             hipLaunchKernelGGL((k_x_inverse_reg<2, 2, 0, false, 8>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
         else
             hipLaunchKernelGGL((k_x_inverse_reg<2, 0, 0, false, 8>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+    } else if (p->xreg && p->rset_x == 2 && ep.kind != ConvEpilogue::kConsensus) {
+        if (ep.kind == ConvEpilogue::kUpdate)
+            hipLaunchKernelGGL((k_x_inverse_reg<2, 2, 0, false, 9>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
+        else
+            hipLaunchKernelGGL((k_x_inverse_reg<2, 0, 0, false, 9>), xg, xb, p->lds_x, st, spec, dst, g, p->ax, ep);
     } else if (p->xreg && ep.kind != ConvEpilogue::kConsensus) {
         if (p->rset_x) {
             if (ep.kind == ConvEpilogue::kUpdate) M3D_LAUNCH_XIR(1, 2);

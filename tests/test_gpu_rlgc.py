@@ -178,8 +178,9 @@ def test_solver_with_register_z_pass_matches_oracle(shape, psf_shape, padded):
                                           ((22, 30, 568), (32, 48, 576)),      # 576 = 8 * 9 * 8
                                           ((22, 28, 1144), (32, 36, 1152)),    # 1152 = 8 * 9 * 2 * 8
                                           ((22, 27, 2040), (32, 36, 2048)),    # 2048 = 8 * 8 * 4 * 8: a fifth wave
-                                          ((22, 27, 2584), (32, 36, 2592))])   # 2592 = 9 * 8 * 4 * 9: radix-9 edges, 288
+                                          ((22, 27, 2584), (32, 36, 2592)),    # 2592 = 9 * 8 * 4 * 9: radix-9 edges, 288
                                                                                # edge items - a fifth wave with elements
+                                          ((22, 27, 640), (32, 36, 648))])     # 648 = 9 * 8 * 9: radix 8 between radix-9 edges
 def test_solver_with_radix8_register_edges_matches_oracle(shape, padded):
     """Padded X lengths 64 m without two radix-9 stages run the register-edge X passes with radix-8 edge stages (round
     3): forward (mirrored and pruned inputs), plain / update inverse, the dual pass with its chained forward transform,
