@@ -1661,22 +1661,23 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
     }
 }
 
-// YP = R0 * R1 * R2 * R3 (R3 may be 1), TW = 4, 2^LCH rows per chunk, NT_ threads.
-template <bool INV, int YP, int R0, int R1, int R2, int R3, int LCH, int NT_>
+// YP = R0 * R1 * R2 * R3 (R3 may be 1), TW = TWC (4; 2 for 2592, whose tile of four columns would be 83 KB), 2^LCH rows per
+// chunk, NT_ threads.
+template <bool INV, int YP, int R0, int R1, int R2, int R3, int LCH, int NT_, int TWC = 4>
 __global__ __launch_bounds__(NT_) void k_y_pass_static(float2 *__restrict__ spec, ConvGeo g, const float2 *__restrict__ tw)
 {
     extern __shared__ float2 lds_ys[];
-    constexpr int TWc = 4, n = YP * TWc, CH = 1 << LCH;
+    constexpr int TWc = TWC, n = YP * TWc, CH = 1 << LCH, IPR = TWC / 2;  // IPR: 16-byte items per row
     const int tid = threadIdx.x;
     const m3d::ConvBox &bx = INV ? g.out : g.in;
     const int z = bx.z0 + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
     float2 *pl = spec + (int64_t)z * g.plane;
     const int lo = INV ? 0 : bx.y0 * TWc, hi = INV ? n : (bx.y0 + bx.ny) * TWc;    // load range (elements)
     const int slo = INV ? bx.y0 * TWc : 0, shi = INV ? (bx.y0 + bx.ny) * TWc : n;  // store range
-    auto elem = [&](int i) {  // 16-byte item i (= half a row) of this tile -> in-plane element offset
-        const int y = i >> 1, y0c = y & ~(CH - 1);
+    auto elem = [&](int i) {  // 16-byte item i (half a row at TW = 4, a row at TW = 2) of this tile -> in-plane element offset
+        const int y = i / IPR, y0c = y & ~(CH - 1);
         const int rows_c = min(CH, YP - y0c);
-        return ((y0c * g.nT + (y - y0c)) << 2) + ((kt * rows_c) << 2) + ((i & 1) << 1);
+        return (y0c * g.nT + (y - y0c)) * TWc + (kt * rows_c) * TWc + ((i % IPR) << 1);
     };
     float4 *l4 = (float4 *)lds_ys;
     constexpr int kU = M3D_KU_Y;
@@ -1718,12 +1719,12 @@ __global__ __launch_bounds__(NT_) void k_y_pass_static(float2 *__restrict__ spec
 }
 
 // Static-geometry form of k_y_forward_mirror (below): core rows of plane sym_src(z) -> all rows of plane z.
-template <int YP, int R0, int R1, int R2, int R3, int LCH, int NT_>
+template <int YP, int R0, int R1, int R2, int R3, int LCH, int NT_, int TWC = 4>
 __global__ __launch_bounds__(NT_) void k_y_forward_mirror_static(const float2 *__restrict__ src, float2 *__restrict__ dst,
                                                                 ConvGeo g, const float2 *__restrict__ tw)
 {
     extern __shared__ float2 lds_yms[];
-    constexpr int TWc = 4, n = YP * TWc, CH = 1 << LCH;
+    constexpr int TWc = TWC, n = YP * TWc, CH = 1 << LCH, IPR = TWC / 2;
     const int tid = threadIdx.x;
     const int z = (g.zmirror ? g.mir.z0 : 0) + blockIdx.x / g.nT, kt = blockIdx.x % g.nT;
     const int zs = sym_src(z, g.mir.z0, g.mir.nz);
@@ -1731,9 +1732,9 @@ __global__ __launch_bounds__(NT_) void k_y_forward_mirror_static(const float2 *_
     float2 *dpl = dst + (int64_t)z * g.plane;
     const int lo = g.mir.y0 * TWc, hi = (g.mir.y0 + g.mir.ny) * TWc;
     auto elem = [&](int i) {
-        const int y = i >> 1, y0c = y & ~(CH - 1);
+        const int y = i / IPR, y0c = y & ~(CH - 1);
         const int rows_c = min(CH, YP - y0c);
-        return ((y0c * g.nT + (y - y0c)) << 2) + ((kt * rows_c) << 2) + ((i & 1) << 1);
+        return (y0c * g.nT + (y - y0c)) * TWc + (kt * rows_c) * TWc + ((i % IPR) << 1);
     };
     float4 *l4 = (float4 *)lds_yms;
     constexpr int kU = M3D_KU_Y;
@@ -1750,10 +1751,10 @@ __global__ __launch_bounds__(NT_) void k_y_forward_mirror_static(const float2 *_
     // the core, which the host checks before choosing this kernel)
     const int y_hi = g.mir.y0 + g.mir.ny;
     for (int i = tid; i < n / 2; i += NT_) {
-        const int y = i >> 1;
+        const int y = i / IPR;
         if (y >= g.mir.y0 && y < y_hi) continue;
         const int ys = y < g.mir.y0 ? 2 * g.mir.y0 - 1 - y : 2 * y_hi - 1 - y;
-        l4[i] = l4[(ys << 1) + (i & 1)];
+        l4[i] = l4[ys * IPR + (i % IPR)];
     }
     __syncthreads();
     y_stage_static<R0, false, YP, YP, TWc, NT_>(lds_yms, tw, tid);
@@ -2204,8 +2205,9 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->TW = knob("M3D_FFT_TW", 4);
     while (p->TW > 1 && (size_t)Yp * p->TW * sizeof(float2) > (size_t)knob("M3D_FFT_YLDS_KB", 72) * 1024) p->TW /= 2;
     p->lds_y = (size_t)Yp * p->TW * sizeof(float2);
-    // rows per X block: 4 real rows (2 packed) when they fit 40 KB, else 2
-    p->RB = ((size_t)2 * Xp * sizeof(float2) <= 40 * 1024) ? knob("M3D_FFT_RB", 4) : 2;
+    // rows per X block: 4 real rows (2 packed) when they fit 42 KB (2592: 41.5 KB, three workgroups per CU; measured
+    // 33.7 -> 31.8 ms per iteration against one packed row per workgroup), else 2
+    p->RB = ((size_t)2 * Xp * sizeof(float2) <= (size_t)knob("M3D_FFT_XLDS_KB", 42) * 1024) ? knob("M3D_FFT_RB", 4) : 2;
     p->lds_x = (size_t)(p->RB / 2) * Xp * sizeof(float2);
     // the X forward pass re-uses its buffer as a staging area of whole 128-byte spectrum lines (4 rows x TW = 4)
     if (p->TW == 4 && p->RB == 4) p->lds_x = std::max(p->lds_x, (size_t)((Xp / 2 + 1 + 3) / 4) * 128);
@@ -2263,6 +2265,17 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     // the static Y kernels spread (butterfly, column group) items over the threads: 972 (forward) / 486 (inverse) items
     // in the radix-9 stages, one round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
     if (p->ystatic && getenv("M3D_FFT_YT") == nullptr) p->ythreads = 1024;
+    // 2592 (2304-pixel sensors): tiles of two columns (41.5 KB, three workgroups per CU), 9 9 8 4, 640 threads - the 576
+    // (butterfly, column) items of a radix-9 stage in one round, 3 x 640 threads per CU
+    if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && Yp == 2592 && p->TW == 2 && p->lch == 7 && p->gy == 4 &&
+        getenv("M3D_FFT_YT") == nullptr) {
+        static const int l2592[4] = {9, 9, 8, 4};
+        p->ystatic = 2592;
+        p->ay.nstages = 4;
+        for (int i = 0; i < 4; ++i) p->ay.radix[i] = l2592[i];
+        p->rset_y = lean(p->ay);
+        p->ythreads = 640;
+    }
     p->xstatic = (knob("M3D_FFT_XSTATIC", 1) && p->xreg && Xp == 2187 && Yp == 2187 && p->TW == 4 && p->RB == 4 &&
                   p->lch == 7 && p->gx == 4 && p->rset_x && p->ax.nstages == 4 && p->ax.radix[1] == 9 &&
                   p->ax.radix[2] == 3) ? 1 : 0;
@@ -2449,6 +2462,8 @@ static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, 
         hipLaunchKernelGGL((k_y_pass_static<INV, 1296, 9, 9, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     else if (p->ystatic == 1152)
         hipLaunchKernelGGL((k_y_pass_static<INV, 1152, 9, 8, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->ystatic == 2592)
+        hipLaunchKernelGGL((k_y_pass_static<INV, 2592, 9, 9, 8, 4, 7, 640, 2>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     else if (p->rset_y == 2)
         hipLaunchKernelGGL((k_y_pass<INV, 2>), grid, block, p->lds_y, st, spec, g, p->ay);
     else if (p->rset_y)
@@ -2505,6 +2520,9 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         else if (p->ystatic == 1728 && one_reflection) M3D_LAUNCH_YMS(1728, 9, 8, 8, 3, 1024);
         else if (p->ystatic == 1296 && one_reflection) M3D_LAUNCH_YMS(1296, 9, 9, 4, 4, 1024);
         else if (p->ystatic == 1152 && one_reflection) M3D_LAUNCH_YMS(1152, 9, 8, 4, 4, 1024);
+        else if (p->ystatic == 2592 && one_reflection)
+            hipLaunchKernelGGL((k_y_forward_mirror_static<2592, 9, 9, 8, 4, 7, 640, 2>), dim3(yplanes * (unsigned)p->nT),
+                               dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);
 #undef M3D_LAUNCH_YMS
         else if (p->rset_y == 2)
             hipLaunchKernelGGL(k_y_forward_mirror<2>, dim3(yplanes * (unsigned)p->nT), dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay);
