@@ -695,6 +695,12 @@ __device__ __forceinline__ void middle_forward(float2 *lds, const AxisPlan &ax, 
         return;                                                                   \
     }
         if constexpr (RSET == 2) {
+            if (gmax == 4 && N == 576 && nt == 256 && (nb == 1 || nb == 2)) {  // 8 [9] 8
+                if (nb == 2) lds_stage<9, false>(lds, 576, 72, 1, 2, 576, ax.tw, tid, 256, 4);
+                else lds_stage<9, false>(lds, 576, 72, 1, 1, 576, ax.tw, tid, 256, 4);
+                __syncthreads();
+                return;
+            }
             if (gmax == 4) {
                 M3D_MID_F(2048, 8, 256, 4, 32, 320)
                 M3D_MID_F(2592, 8, 288, 4, 36, 320)  // 9 [8 4] 9
@@ -736,6 +742,12 @@ __device__ __forceinline__ void middle_inverse(float2 *lds, const AxisPlan &ax, 
         return;                                                                  \
     }
         if constexpr (RSET == 2) {
+            if (gmax == 4 && N == 576 && nt == 256 && (nb == 1 || nb == 2)) {
+                if (nb == 2) lds_stage<9, true>(lds, 576, 72, 1, 2, 576, ax.tw, tid, 256, 4);
+                else lds_stage<9, true>(lds, 576, 72, 1, 1, 576, ax.tw, tid, 256, 4);
+                __syncthreads();
+                return;
+            }
             if (gmax == 4) {
                 M3D_MID_I(2048, 8, 256, 4, 32, 320)
                 M3D_MID_I(2592, 8, 288, 4, 36, 320)
@@ -2253,12 +2265,13 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     // radix list is private to the Y passes (the spectrum only ever meets the OTF, which the same passes produce).
     if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && p->TW == 4 && p->lch == 7 && p->gy == 4 &&
         getenv("M3D_FFT_YT") == nullptr) {
-        static const int lists[][5] = {{2048, 8, 8, 8, 4}, {1728, 9, 8, 8, 3}, {1296, 9, 9, 4, 4}, {1152, 9, 8, 4, 4}};
+        static const int lists[][5] = {{2048, 8, 8, 8, 4}, {1728, 9, 8, 8, 3}, {1296, 9, 9, 4, 4}, {1152, 9, 8, 4, 4},
+                                       {576, 9, 8, 8, 1}};
         for (const auto &l : lists)
             if (Yp == l[0]) {
                 p->ystatic = Yp;
-                p->ay.nstages = 4;
-                for (int i = 0; i < 4; ++i) p->ay.radix[i] = l[1 + i];
+                p->ay.nstages = l[4] > 1 ? 4 : 3;
+                for (int i = 0; i < p->ay.nstages; ++i) p->ay.radix[i] = l[1 + i];
                 p->rset_y = lean(p->ay);  // (the run-time mirror pass of a deep pad remains reachable: radix-8 build)
             }
     }
@@ -2464,6 +2477,8 @@ static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, 
         hipLaunchKernelGGL((k_y_pass_static<INV, 1152, 9, 8, 4, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     else if (p->ystatic == 2592)
         hipLaunchKernelGGL((k_y_pass_static<INV, 2592, 9, 9, 8, 4, 7, 640, 2>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+    else if (p->ystatic == 576)
+        hipLaunchKernelGGL((k_y_pass_static<INV, 576, 9, 8, 8, 1, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     else if (p->rset_y == 2)
         hipLaunchKernelGGL((k_y_pass<INV, 2>), grid, block, p->lds_y, st, spec, g, p->ay);
     else if (p->rset_y)
@@ -2520,6 +2535,7 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
         else if (p->ystatic == 1728 && one_reflection) M3D_LAUNCH_YMS(1728, 9, 8, 8, 3, 1024);
         else if (p->ystatic == 1296 && one_reflection) M3D_LAUNCH_YMS(1296, 9, 9, 4, 4, 1024);
         else if (p->ystatic == 1152 && one_reflection) M3D_LAUNCH_YMS(1152, 9, 8, 4, 4, 1024);
+        else if (p->ystatic == 576 && one_reflection) M3D_LAUNCH_YMS(576, 9, 8, 8, 1, 1024);
         else if (p->ystatic == 2592 && one_reflection)
             hipLaunchKernelGGL((k_y_forward_mirror_static<2592, 9, 9, 8, 4, 7, 640, 2>), dim3(yplanes * (unsigned)p->nT),
                                dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw);

@@ -431,7 +431,8 @@ def test_static_geometry_kernels_equal_the_generic_ones(monkeypatch):
 
 
 @pytest.mark.parametrize("ly,yp", [(2002, 2048), (1680, 1728), (1250, 1296), (1100, 1152),
-                                   (2546, 2592)])     # tiles of two columns (9 9 8 4 at 640 threads)
+                                   (2546, 2592),      # tiles of two columns (9 9 8 4 at 640 threads)
+                                   (530, 576)])       # three stages (9 8 8)
 def test_static_y_kernels_of_other_lengths_equal_the_generic_ones(monkeypatch, ly, yp):
     """Padded Y lengths 2048 / 1728 / 1296 / 1152 run static Y kernels with their own radix lists (8 8 8 4, 9 8 8 3,
     9 9 4 4, 9 8 4 4: forward, inverse with cropped output, the mirrored forward pass); M3D_FFT_YSTATIC=0 sends the same

@@ -79,7 +79,7 @@ def test_pad_psf_places_every_sample_where_the_reference_does(psf_shape, shape, 
                                    # X lengths with radix-8 register edge stages
                                    (16, 27, 128), (16, 32, 192), (8, 36, 576), (8, 27, 1536), (8, 32, 2048),
                                    # 2592: radix-9 edges with 288 edge items (X), column tiles of two (Y: 83 KB at four)
-                                   (8, 27, 2592), (8, 2592, 36), (8, 27, 648)])
+                                   (8, 27, 2592), (8, 2592, 36), (8, 27, 648), (16, 576, 36)])
 def test_fft_conv_with_transfer_function_views(shape):
     rl = pkg("utils.rlgc")
     rng = np.random.default_rng(2)
