@@ -39,6 +39,10 @@ typedef enum m3d_status {
 typedef enum m3d_dtype { M3D_U16 = 0, M3D_F32 = 1, M3D_F16 = 2, M3D_I16 = 3 } m3d_dtype;
 
 int m3d_version(void);
+/* SHA-256 (64 hex digits) of the sources this library was compiled from (csrc/build.py links it in); the Python
+ * binding compares it with the tree's and refuses a stale library.  No reference counterpart (the reference has no
+ * native code): build hygiene of this boundary. */
+const char *m3d_source_hash(void);
 const char *m3d_status_string(int status);
 /* last HIP / rocFFT error text of the calling thread (host string, never NULL) */
 const char *m3d_last_error(void);
@@ -69,11 +73,18 @@ typedef struct m3d_rlgc_params {
 } m3d_rlgc_params;
 
 #define M3D_RLGC_TRACE_CAP 512
+/* m3d_rlgc_result.engine_flags */
+#define M3D_ENGINE_X_STATIC 1     /* register-edge X passes compiled for the 2187-point axis              */
+#define M3D_ENGINE_Y_STATIC 2     /* static-geometry Y passes                                             */
+#define M3D_ENGINE_SPLIT_CHAIN 4  /* photon split fused between the Hu and the ratio convolutions' X passes */
+#define M3D_ENGINE_UPDATE_CHAIN 8 /* update pass chained into the next forward transform                  */
+#define M3D_ENGINE_Z_REGISTER 16  /* register Z pass (padded Z = 32 / 64 / 128 / 256)                      */
+
 typedef struct m3d_rlgc_result {
     int32_t iterations;  /* completed multiplicative updates (num_iters, rlgc.py:698)      */
     int32_t stop_reason; /* 1 restore_previous_recon, 2 limit, 3 max_delta, 4 max_iterations */
     int32_t n_trace;     /* entries valid in the arrays below (<= M3D_RLGC_TRACE_CAP)       */
-    int32_t reserved;
+    int32_t engine_flags; /* which kernel families ran (diagnostic; tests assert on it): M3D_ENGINE_* below */
     double kld_image[M3D_RLGC_TRACE_CAP];          /* rlgc.py:626 */
     double kld_split1[M3D_RLGC_TRACE_CAP];         /* rlgc.py:627 */
     double kld_split2[M3D_RLGC_TRACE_CAP];         /* rlgc.py:628 */

@@ -17,6 +17,7 @@ _lib: ctypes.CDLL | None = None
 
 M3D_U16, M3D_F32, M3D_F16, M3D_I16 = 0, 1, 2, 3
 TRACE_CAP = 512
+ENGINE_X_STATIC, ENGINE_Y_STATIC, ENGINE_SPLIT_CHAIN, ENGINE_UPDATE_CHAIN, ENGINE_Z_REGISTER = 1, 2, 4, 8, 16
 
 
 class M3DError(RuntimeError):
@@ -56,7 +57,7 @@ class RLGCResult(ctypes.Structure):
         ("iterations", c_int32),
         ("stop_reason", c_int32),
         ("n_trace", c_int32),
-        ("reserved", c_int32),
+        ("engine_flags", c_int32),
         ("kld_image", ctypes.c_double * TRACE_CAP),
         ("kld_split1", ctypes.c_double * TRACE_CAP),
         ("kld_split2", ctypes.c_double * TRACE_CAP),
@@ -95,6 +96,7 @@ _L3 = c_int64 * 3
 
 _SIGNATURES = {
     "m3d_version": (c_int, []),
+    "m3d_source_hash": (c_char_p, []),
     "m3d_status_string": (c_char_p, [c_int]),
     "m3d_last_error": (c_char_p, []),
     "m3d_next_fft_size": (c_int, [c_int]),
@@ -234,11 +236,29 @@ def lib() -> ctypes.CDLL:
 
         handle = ctypes.CDLL(str(_LIB_PATH), mode=ctypes.RTLD_GLOBAL)
         for name, (restype, argtypes) in _SIGNATURES.items():
-            fn = getattr(handle, name)
+            fn = getattr(handle, name, None)
+            if fn is None:
+                raise ImportError(f"{_LIB_PATH} lacks {name}: rebuild it (python merfish3d-analysis_amd/csrc/build.py)")
             fn.restype = restype
             fn.argtypes = argtypes
+        _refuse_stale_library(handle)
         _lib = handle
     return _lib
+
+
+def _refuse_stale_library(handle) -> None:
+    """A library built from other sources than the tree's is not the product (and, half-rebuilt, can abort the
+    process inside the HIP runtime - DESIGN.md section 11).  Checked where the sources travel with the library."""
+    from . import _buildcheck
+
+    if not any(_buildcheck.CSRC.glob("*.hip")):
+        return  # binary-only install: nothing to compare with
+    built, tree = handle.m3d_source_hash().decode(), _buildcheck.source_hash()
+    if built != tree:
+        raise ImportError(
+            f"{_LIB_PATH} was built from sources {built[:16]}, the tree holds {tree[:16]}: rebuild it "
+            "(python merfish3d-analysis_amd/csrc/build.py).  There is no CPU fallback."
+        )
 
 
 def check(status: int, what: str = "") -> None:

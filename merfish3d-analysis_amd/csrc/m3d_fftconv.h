@@ -76,6 +76,8 @@ struct ConvEpilogue {
     float2 *chain = nullptr;
 };
 bool fftconv_update_chain_supported(const struct FftConvPlan *p);
+// M3D_ENGINE_X_STATIC | M3D_ENGINE_Y_STATIC | M3D_ENGINE_Z_REGISTER of this plan's kernel selection
+int fftconv_engine_flags(const struct FftConvPlan *p);
 // order-preserving map float -> uint32 (atomicMin / atomicMax on floats of either sign)
 __host__ __device__ inline unsigned int float_key(float f)
 {

@@ -2181,6 +2181,8 @@ ConvGeo geo_of(const FftConvPlan *p, const m3d::ConvBox *in = nullptr, const m3d
 
 namespace m3d {
 
+constexpr size_t kDefaultLdsLimit = 64 * 1024;
+
 int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
 {
     *out = nullptr;
@@ -2344,36 +2346,56 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->ax.pos = (const int *)(d + Xp + Yp + Zp);
     p->ay.pos = nullptr;
     p->az.pos = nullptr;
-    // allow > 64 KB of dynamic LDS where needed
-    const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-    (void)hipFuncSetAttribute((const void *)k_x_forward<0>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_forward<1>, attr, (int)p->lds_x);
-    const int lds_dual = (int)((size_t)p->dual_rows * Xp * sizeof(float2));
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0, false>, attr, lds_dual);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1, false>, attr, lds_dual);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<0, true>, attr, lds_dual);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse_dual<1, true>, attr, lds_dual);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 0>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 0>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 1>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 1>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<0, 2>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_x_inverse<1, 2>, attr, (int)p->lds_x);
-    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<0>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror<1>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 768>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 1024>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 1024>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 1024>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass<false, 0>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass<false, 1>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass<true, 0>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_y_pass<true, 1>, attr, (int)p->lds_y);
-    (void)hipFuncSetAttribute((const void *)k_z_conv<2>, attr, (int)p->lds_z);
-    (void)hipFuncSetAttribute((const void *)k_z_conv<0>, attr, (int)p->lds_z);
-    (void)hipFuncSetAttribute((const void *)k_z_conv<1>, attr, (int)p->lds_z);
+    // Dynamic LDS above the 64 KB every kernel may use by default: the limit is raised on the kernels THIS plan launches
+    // and nowhere else (a Y column tile of the 2187-point axis is 70 KB; X, dual and Z buffers above 64 KB are refused).
+    // Round 3 set it on 27 instantiations with the status discarded; a library whose host stubs named a kernel that
+    // its code object lacked then aborted inside the runtime at this point.
+    if (p->lds_x > kDefaultLdsLimit || (size_t)p->dual_rows * Xp * sizeof(float2) > kDefaultLdsLimit ||
+        p->lds_z > kDefaultLdsLimit) {
+        fftconv_destroy(p);
+        return M3D_ERR_UNSUPPORTED;
+    }
+    int rc = M3D_OK;
+    auto allow = [&](const void *fn) {
+        if (rc != M3D_OK || p->lds_y <= kDefaultLdsLimit) return;
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_y);
+        if (e != hipSuccess) {
+            set_err("hipFuncSetAttribute(MaxDynamicSharedMemorySize) on a Y pass", hipGetErrorString(e));
+            rc = M3D_ERR_HIP;
+        }
+    };
+    if (p->ystatic == 2187 && p->ythreads == 1024) {
+        allow((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 1024>);
+        allow((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 1024>);
+        allow((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 1024>);
+    } else if (p->ystatic == 2187) {
+        allow((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>);
+        allow((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 768>);
+        allow((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 768>);
+    } else if (p->ystatic && p->lds_y > kDefaultLdsLimit) {  // the other static tiles are 64 KB at most by construction
+        fftconv_destroy(p);
+        return M3D_ERR_UNSUPPORTED;
+    }
+    if (!p->ystatic) {
+        if (p->rset_y == 2) {
+            allow((const void *)k_y_pass<false, 2>);
+            allow((const void *)k_y_pass<true, 2>);
+        } else if (p->rset_y) {
+            allow((const void *)k_y_pass<false, 1>);
+            allow((const void *)k_y_pass<true, 1>);
+        } else {
+            allow((const void *)k_y_pass<false, 0>);
+            allow((const void *)k_y_pass<true, 0>);
+        }
+    }
+    // the run-time mirror pass also serves static plans whose pad is deeper than one reflection
+    if (p->rset_y == 2) allow((const void *)k_y_forward_mirror<2>);
+    else if (p->rset_y) allow((const void *)k_y_forward_mirror<1>);
+    else allow((const void *)k_y_forward_mirror<0>);
+    if (rc != M3D_OK) {
+        fftconv_destroy(p);
+        return rc;
+    }
     *out = p;
     return M3D_OK;
 }
@@ -2606,6 +2628,13 @@ int fftconv_to_rows(const FftConvPlan *p, const float *src, const float2 *otf, i
 
 bool fftconv_real_otf_supported(const FftConvPlan *p) { return p && p->zreg != 0; }
 bool fftconv_update_chain_supported(const FftConvPlan *p) { return p && p->xstatic && p->TW == 4 && p->RB == 4; }
+
+int fftconv_engine_flags(const FftConvPlan *p)
+{
+    if (!p) return 0;
+    return (p->xstatic ? M3D_ENGINE_X_STATIC : 0) | (p->ystatic ? M3D_ENGINE_Y_STATIC : 0) |
+           (p->zreg ? M3D_ENGINE_Z_REGISTER : 0);
+}
 
 __global__ void k_otf_abs2(const float2 *__restrict__ otf, float *__restrict__ out, int64_t n)
 {

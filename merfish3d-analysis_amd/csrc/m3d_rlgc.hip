@@ -655,7 +655,7 @@ static int g_fft_engine = 0;  // 0: fused in-LDS engine (rocFFT only as fallback
 
 extern "C" {
 
-int m3d_version(void) { return 101; }
+int m3d_version(void) { return 102; }
 
 int m3d_set_fft_engine(int engine)
 {
@@ -752,7 +752,7 @@ int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], i
     if (g_fft_engine != 1) {
         rc = m3d::fftconv_create(g.Zp, g.Yp, g.Xp, &p->fc);
         if (rc != M3D_OK && rc != M3D_ERR_UNSUPPORTED) {
-            set_err("fftconv_create", "table allocation failed");
+            if (rc == M3D_ERR_OUT_OF_MEMORY) set_err("fftconv_create", "table allocation failed");
             m3d_rlgc_plan_destroy(p);
             return rc;
         }
@@ -1191,7 +1191,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         return M3D_OK;
     };
 
-    if (res) memset(res, 0, sizeof(*res));
+    if (res) {
+        memset(res, 0, sizeof(*res));
+        res->engine_flags = m3d::fftconv_engine_flags(p->fc) | (split_chain ? M3D_ENGINE_SPLIT_CHAIN : 0) |
+                            (chain_update ? M3D_ENGINE_UPDATE_CHAIN : 0);
+    }
     double prev1 = INFINITY, prev2 = INFINITY;
     int num_iters = 0, stop = 0;
     float *result = nullptr;

@@ -391,6 +391,7 @@ class RLGCInfo:
     conv_ms_total: float = 0.0   # only with profile=True: device time inside fft_conv
     conv_calls: int = 0
     fused_engine: bool = True
+    engine_flags: int = 0        # _hip.ENGINE_* bits: which kernel families ran (diagnostic, asserted by tests)
     kernel_ms: tuple = ()        # profile + fused engine: x fwd, y fwd, z conv, y inv, x inv
     loop_ms: float = 0.0         # profile: device time of the whole iteration loop
 
@@ -509,6 +510,7 @@ def rlgc_device(
         conv_ms_total=float(result.conv_ms_total),
         conv_calls=int(result.conv_calls),
         fused_engine=bool(result.fused_engine),
+        engine_flags=int(result.engine_flags),
         kernel_ms=tuple(float(v) for v in result.kernel_ms),
         loop_ms=float(result.loop_ms),
     )

@@ -1,8 +1,7 @@
 #!/bin/bash
-# k_split_ratio's rocprofv3 average at several image brightnesses (usage: gpu_split_brightness.sh tag [lib.so in scratch_libs])
+# k_split_ratio's rocprofv3 average at several image brightnesses (usage: gpu_split_brightness.sh tag)
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out; mkdir -p $O
-tag=${1:-new}; L=$R/merfish3d-analysis_amd/csrc/libm3d_hip.so
-if [ -n "$2" ]; then cp $L /tmp/orig_split.so; cp $R/scratch_libs/$2 $L; fi
+tag=${1:-new}
 cd /tmp && export TMPDIR=/tmp
 : > $O/split_brightness_$tag.txt
 for mean in ${COUNTS:-100 1000 10000 60000}; do
@@ -12,4 +11,3 @@ for mean in ${COUNTS:-100 1000 10000 60000}; do
   line=$(grep k_split_ratio $f | awk -F, '{printf "calls %s avg_ms %.3f min_ms %.3f max_ms %.3f", $(NF-6), $(NF-4)/1e6, $(NF-2)/1e6, $(NF-1)/1e6}')
   echo "$tag mean_count=$mean k_split_ratio: $line | $(grep '^mean' /tmp/sb_out.txt)" | tee -a $O/split_brightness_$tag.txt
 done
-if [ -n "$2" ]; then cp /tmp/orig_split.so $L; fi

@@ -1,0 +1,126 @@
+"""GPU parity at the HEADLINE lateral geometry, directly against the oracle.
+
+BASELINE.json configs[1] pads a 64 x 2048 x 2048 tile to 128 x 2187 x 2187, and at 2187 = 9 * 9 * 9 * 3 the plan
+selects kernels compiled for that geometry alone (`k_x_forward_reg<1, 2187>`, `k_x_inverse_split_chain<..., 2187>`,
+`k_x_inverse_dual_reg<1, true, 2187>`, `k_x_inverse_reg<1, 2, 2187, true>`, `k_y_pass_static<..., 2187, 9, 9, 9, 3>`,
+`k_y_forward_mirror_static<2187, ...>`): literal stages, register twiddles, chained tails, a radix list that exists
+nowhere else.  Until round 4 they were compared with the run-time-geometry kernels only (which meet the oracle at other
+lengths).  Here the NumPy restatement (oracle/rlgc_ref.py, pinned bit for bit by the reference-run goldens) is the
+checker at the true lateral size, on volumes thin enough in Z for the oracle to finish in under a minute; the Z passes
+do not depend on the lateral size and meet the oracle at padded Z = 32 / 64 / 128 in test_gpu_rlgc.py.
+
+Reference: utils/rlgc.py:316-350 (fft_conv), :616-736 (the iteration).
+"""
+
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import rlgc_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+VOLUME_TOL = 1e-4   # of the volume's peak (north_star: floats within 1e-4)
+
+
+def _gaussian_psf(shape, sigma):
+    zz, yy, xx = np.meshgrid(*[np.arange(n, dtype=np.float64) - n // 2 for n in shape], indexing="ij")
+    psf = np.exp(-0.5 * ((zz / sigma[0]) ** 2 + (yy / sigma[1]) ** 2 + (xx / sigma[2]) ** 2))
+    return (psf / psf.sum()).astype(np.float32)
+
+
+def _phantom(shape, sigma, n_spots, seed):
+    """Poisson image of blurred point emitters on a background (separable blur: cheap at 2100 x 2100)."""
+    from scipy.ndimage import gaussian_filter
+
+    rng = np.random.default_rng(seed)
+    vol = np.zeros(shape, dtype=np.float32)
+    idx = tuple(rng.integers(0, s, size=n_spots) for s in shape)
+    np.add.at(vol, idx, rng.uniform(400, 1500, size=n_spots).astype(np.float32))
+    img = rng.poisson(gaussian_filter(vol, sigma, mode="reflect").astype(np.float64) * 40.0 + 20.0)
+    return np.clip(img, 0, 65535).astype(np.uint16)
+
+
+@pytest.fixture
+def fast_oracle_ffts(monkeypatch):
+    """pocketfft worker threads for the oracle's transforms (same mathematics as numpy.fft, last-bit differences -
+    far below the 1e-4 these tests allow); the elementwise passes stay NumPy."""
+    import os
+
+    monkeypatch.setattr(rlgc_ref, "FFT_WORKERS", min(16, os.cpu_count() or 1))
+
+
+def test_solver_at_2187_with_the_reference_stream_injected(fast_oracle_ffts):
+    """Image 6 x 2100 x 2100, PSF 3 x 9 x 9 -> FFT volume 8 x 2187 x 2187.  The oracle runs with NumPy's binomial
+    stream (what the reference-run goldens use) and records its splits; the HIP solver takes them through the injection
+    hook - which feeds `k_x_inverse_split_chain`, the kernel the bench runs - so every float of the iteration is
+    comparable: iteration count and stop reason exactly, KL traces to rtol 1e-4, the volume to 1e-4 of its peak."""
+    rl, hip = pkg("utils.rlgc"), pkg("_hip")
+    shape, psf_shape = (6, 2100, 2100), (3, 9, 9)
+    img = _phantom(shape, (0.8, 1.5, 1.5), 12000, seed=41)
+    psf = _gaussian_psf(psf_shape, (0.8, 1.5, 1.5))
+    n_iter = 3
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, rinfo = rlgc_ref.rlgc(img, psf, rng="numpy", return_info=True, record_splits=True, max_iterations=n_iter)
+    assert tuple(rinfo.padded_shape) == (8, 2187, 2187)
+    splits = np.stack([rlgc_ref.remove_padding_zyx(s, rinfo.pad_width) for s in rinfo.splits[:n_iter]])
+    rinfo.splits.clear()
+    img_t, psf_t = torch.from_numpy(img).to(DEV), torch.from_numpy(psf).to(DEV)
+    out, info = rl.rlgc_device(img_t, psf_t, injected_splits=torch.from_numpy(splits).to(DEV), max_iterations=n_iter)
+    want_flags = hip.ENGINE_X_STATIC | hip.ENGINE_Y_STATIC | hip.ENGINE_SPLIT_CHAIN | hip.ENGINE_UPDATE_CHAIN
+    assert info.fused_engine and info.engine_flags & want_flags == want_flags, info.engine_flags
+    assert tuple(info.padded_shape) == (8, 2187, 2187)
+    assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason) == (n_iter, "max_iterations")
+    np.testing.assert_allclose(info.kld_image[:n_iter], rinfo.kld_image[:n_iter], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.kld_split1[:n_iter], rinfo.kld_split1[:n_iter], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.kld_split2[:n_iter], rinfo.kld_split2[:n_iter], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.updated_fraction, rinfo.updated_fraction, atol=1e-4)
+    np.testing.assert_allclose(info.max_relative_delta, rinfo.max_relative_delta, rtol=2e-3, atol=1e-6)
+    got = out.cpu().numpy()
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    assert err < VOLUME_TOL, err
+    # what DataRegistration stores (clip -> uint16, truncation): never more than one count apart
+    a, b = np.clip(got, 0, 65535).astype(np.uint16).astype(np.int64), np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64)
+    assert np.abs(a - b).max() <= 1 and np.mean(a != b) < 5e-3, (np.abs(a - b).max(), np.mean(a != b))
+
+    # The kernel's own Philox stream at this geometry: the stand-alone sampler is bit-identical to oracle/philox.py
+    # (test_gpu_rlgc.py); injecting ITS draws must reproduce the in-kernel draws bit for bit - same voxel counter,
+    # same iteration number, same rows - so the sampler inside the 2187 split chain is pinned to the oracle as well.
+    kernels = pkg("kernels")
+    own = torch.stack([kernels.rlgc_debug_split(img_t, 42, it) for it in range(n_iter)])
+    out_inj, info_inj = rl.rlgc_device(img_t, psf_t, rng_seed=42, injected_splits=own, max_iterations=n_iter)
+    out_inj = out_inj.clone()
+    out_own, info_own = rl.rlgc_device(img_t, psf_t, rng_seed=42, max_iterations=n_iter)
+    assert torch.equal(out_inj, out_own)
+    assert list(info_inj.kld_split1[:n_iter]) == list(info_own.kld_split1[:n_iter])
+    rl.clear_rlgc_caches(clear_memory_pool=True)
+
+
+def test_solver_at_2187_runs_to_its_stop_rule_like_the_oracle(fast_oracle_ffts):
+    """A dimmer, thinner image (2 x 2100 x 2100 -> FFT volume 4 x 2187 x 2187) taken to the stop rule with the
+    reference's stream injected: the restore / limit / max_delta decisions and the returned estimate at the headline
+    lateral geometry, against the oracle."""
+    rl = pkg("utils.rlgc")
+    shape, psf_shape = (2, 2100, 2100), (3, 9, 9)
+    img = _phantom(shape, (0.6, 1.5, 1.5), 3000, seed=43)
+    psf = _gaussian_psf(psf_shape, (0.6, 1.5, 1.5))
+    cap = 12
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, rinfo = rlgc_ref.rlgc(img, psf, rng="numpy", return_info=True, record_splits=True, max_iterations=cap)
+    assert tuple(rinfo.padded_shape) == (4, 2187, 2187)
+    splits = np.stack([rlgc_ref.remove_padding_zyx(s, rinfo.pad_width) for s in rinfo.splits])
+    rinfo.splits.clear()
+    out, info = rl.rlgc_device(torch.from_numpy(img).to(DEV), torch.from_numpy(psf).to(DEV),
+                               injected_splits=torch.from_numpy(splits).to(DEV), max_iterations=cap)
+    assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
+    n = len(rinfo.kld_split1)
+    np.testing.assert_allclose(info.kld_split1[:n], rinfo.kld_split1, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(info.kld_split2[:n], rinfo.kld_split2, rtol=1e-4, atol=1e-7)
+    err = float(np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert err < VOLUME_TOL, err
+    rl.clear_rlgc_caches(clear_memory_pool=True)

@@ -79,9 +79,16 @@ def test_pad_psf_places_every_sample_where_the_reference_does(psf_shape, shape, 
                                    # X lengths with radix-8 register edge stages
                                    (16, 27, 128), (16, 32, 192), (8, 36, 576), (8, 27, 1536), (8, 32, 2048),
                                    # 2592: radix-9 edges with 288 edge items (X), column tiles of two (Y: 83 KB at four)
-                                   (8, 27, 2592), (8, 2592, 36), (8, 27, 648), (16, 576, 36)])
-def test_fft_conv_with_transfer_function_views(shape):
+                                   (8, 27, 2592), (8, 2592, 36), (8, 27, 648), (16, 576, 36),
+                                   # the headline lateral geometry (BASELINE configs[1] pads 2048 to 2187 = 9 9 9 3):
+                                   # static X and Y kernels together, each axis alone with the run-time partner
+                                   (8, 2187, 2187), (8, 27, 2187), (8, 2187, 36)])
+def test_fft_conv_with_transfer_function_views(shape, monkeypatch):
     rl = pkg("utils.rlgc")
+    if int(np.prod(shape)) > 10_000_000:   # pocketfft worker threads for the oracle's transforms at 38 M voxels
+        import os
+
+        monkeypatch.setattr(rlgc_ref, "FFT_WORKERS", min(16, os.cpu_count() or 1))
     rng = np.random.default_rng(2)
     img = rng.uniform(0, 100, size=shape).astype(np.float32)
     psf_pad = rlgc_ref.pad_psf(_psf((5, 7, 7)), shape, True)
