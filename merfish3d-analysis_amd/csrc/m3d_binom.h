@@ -152,7 +152,14 @@ M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, ui
     U32x4 r = philox4x32<kSplitRounds>(c, k0, k1);
     const int rb = (int)(n & 63u);
     uint32_t q = n >> 6;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the low rb bits of (y:x) as one 64-bit mask: seven instructions instead of the twelve of the two-word form below
+    // (same bits, same count)
+    const uint64_t keep = ~(~0ull << rb);  // rb < 64
+    uint32_t acc = (uint32_t)(popc32(r.x & (uint32_t)keep) + popc32(r.y & (uint32_t)(keep >> 32)));
+#else
     uint32_t acc = popc32(r.x & low_mask(rb > 32 ? 32 : rb)) + popc32(r.y & low_mask(rb > 32 ? rb - 32 : 0));
+#endif
     const uint32_t q0 = q < kBinomQMax ? q : kBinomQMax;
     const uint32_t ones = (uint32_t)(popc32(r.z) + popc32(r.w));
     if (q0 >= 2u)

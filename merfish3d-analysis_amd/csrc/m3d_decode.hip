@@ -528,7 +528,7 @@ int m3d_decode_pixels(const float *stack, int32_t B, int64_t N, const float *bac
     const int64_t trips = (N + 63) / 64;
     int64_t blocks = (trips + 3) / 4;
     // blocks per CU of the grid-stride launch: 116 registers per lane allow four waves per SIMD = four resident blocks
-    static const int per_cu = [] { const char *e = getenv("M3D_DECODE_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : 4; }();
+    constexpr int per_cu = 4;
     if (blocks < 1) blocks = 1;
     if (blocks > 256 * (int64_t)per_cu) blocks = 256 * (int64_t)per_cu;
     hipStream_t st = (hipStream_t)stream;

@@ -130,9 +130,6 @@ struct SplitArgs {
     uint64_t seed;
     BinomTables tables;
     SplitPartial *partial;  // fftconv_split_chain_blocks() records
-    // optional: the iteration number is read from device memory instead (an iteration captured in a hipGraph is replayed
-    // with the same kernel arguments; the counter is advanced by a one-thread kernel inside the graph)
-    const uint32_t *iteration_dev = nullptr;
 };
 bool fftconv_split_chain_supported(const FftConvPlan *p);
 int64_t fftconv_split_chain_blocks(const FftConvPlan *p, const ConvBox *core);

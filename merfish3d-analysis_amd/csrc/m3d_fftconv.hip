@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "m3d_common.h"
@@ -1413,14 +1414,17 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
     // holds 128 registers; the register twiddles of the other static X kernels cost it 6 %)
     middle_inverse<RSET, NS>(lds_sp, ax, 1, N, tid, nt, g.GX);
     const float eps = 1e-4f;
-    const uint32_t iteration = sa.iteration_dev ? *sa.iteration_dev : sa.iteration;
+    const uint32_t iteration = sa.iteration;
     float sums[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // A, Bim, B1, B2, Tim, T1, T2 of this thread's 18 voxels
     if (tid < S) {
         const T *image = (const T *)sa.image;
         const int64_t plane0 = (int64_t)(z - g.out.z0) * g.out.ny;
         // counts (and injected splits) of both rows: requested before the last inverse stage; rows and columns outside
         // the box are clamped into it (their values are not used)
-        float cnt[2][9], inj[2][9];
+        // (a uint16 image's count is the draw's n as it stands: kept as an integer, converted once for the arithmetic)
+        using Count = typename std::conditional<sizeof(T) == 2, uint32_t, float>::type;
+        Count cnt[2][9];
+        float inj[2][9];
         int64_t irows[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -1428,7 +1432,7 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 const int xi = min(max(tid + S * q - g.out.x0, 0), g.out.nx - 1);
-                cnt[r][q] = load_count(image, irows[r] + xi);
+                cnt[r][q] = (Count)image[irows[r] + xi];
                 inj[r][q] = sa.injected ? sa.injected[irows[r] + xi] : 0.0f;
             }
         }
@@ -1453,13 +1457,18 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
                 const int x = tid + S * q;
                 if (x < g.out.x0 || x >= x_hi) continue;
                 const float h = r ? v[q].y : v[q].x;
-                const float val = cnt[r][q];
+                const float val = (float)cnt[r][q];
                 float s1;
                 if (sa.injected) {
                     s1 = inj[r][q];
                 } else {
-                    const float vt = val > 0.0f ? val : 0.0f;
-                    const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);  // astype(int64) truncation, rlgc.py:619
+                    uint32_t n;
+                    if constexpr (sizeof(T) == 2) {
+                        n = cnt[r][q];
+                    } else {
+                        const float vt = val > 0.0f ? val : 0.0f;
+                        n = (uint32_t)fminf(vt, 1048576.0f);  // astype(int64) truncation, rlgc.py:619
+                    }
                     s1 = (float)m3d::binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + (x - g.out.x0)), iteration,
                                                                       sa.seed, sa.tables);
                 }
@@ -1476,7 +1485,11 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
                     sums[5] += a * (la - __builtin_amdgcn_logf(b1));
                     sums[6] += a * (la - __builtin_amdgcn_logf(b2));
                 }
-                const float inv = m3d::rn_div(1.0f, 0.5f * (h + 1e-12f));  // rlgc.py:654-668
+                // mask * split / (0.5 * (Hu + 1e-12)), rlgc.py:654-668: one reciprocal serves both quotients.  v_rcp_f32 (1 ulp)
+                // instead of the correctly rounded quotient's fourteen instructions: the transforms that consume the
+                // ratios round coarser, the dual pass multiplies by 1 / update_norm the same way, and this kernel is bound
+                // by its vector instructions
+                const float inv = __builtin_amdgcn_rcpf(0.5f * (h + 1e-12f));
                 if (r == 0) {
                     p1[q].x = s1 * inv;
                     p2[q].x = s2 * inv;
@@ -2099,8 +2112,8 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis
 #endif
     // X axis with two or more radix-9 stages: one of them goes last, so that both outer stages are radix 9 and can
     // run in registers (k_x_forward_reg / k_x_inverse_reg)
-    const bool nine_last = x_axis && c3 >= 4 && getenv("M3D_FFT_XREG_ORDER") == nullptr;
-    static const bool small_pow2 = getenv("M3D_FFT_BIG_RADIX") == nullptr;  // 4,4,4,2 beat 16,8 (VGPRs)
+    const bool nine_last = x_axis && c3 >= 4;
+    constexpr bool small_pow2 = true;  // 4,4,4,2 beat 16,8 (VGPRs; measured in round 1)
     // X axis of a length 64 m <= 2048 that has no two radix-9 stages (2048, 1728, 1536, 1152, 1024, 576, ...): a radix-8
     // stage first and last, which the same register-edge kernels run (edge radix 8; M3D_FFT_XREG8=0 disables)
     const bool eight_edges = x_axis && !nine_last && c2 >= 6 && n / 8 <= 256 && small_pow2 &&
@@ -2116,10 +2129,10 @@ bool factor_23(int n, int *radix, int *nstages, bool z_axis = false, bool x_axis
     // (measured 1.93 -> 1.71 ms); M3D_FFT_Z_RADIX4=1 keeps 4, 4, 4, 2.
     // X axis without register edge stages (in-LDS kernels): the same rule - 2048 = 8 * 8 * 8 * 4 is four LDS stages
     // per transform instead of the six of 4 * 4 * 4 * 4 * 4 * 2 (M3D_FFT_X_RADIX4=1 keeps the radix-4 lists)
-    const bool x_eights = x_axis && getenv("M3D_FFT_X_RADIX4") == nullptr;  // (also between two radix-9 edge stages:
+    const bool x_eights = x_axis;  // (also between two radix-9 edge stages:
                                                                              //  2592 = 9 8 4 9 instead of 9 4 4 2 9)
-    const bool y_eights = !x_axis && !z_axis && getenv("M3D_FFT_Y_RADIX4") == nullptr;  // run-time Y kernels alike
-    if ((x_eights || y_eights || (z_axis && getenv("M3D_FFT_Z_RADIX4") == nullptr)) && small_pow2) {
+    const bool y_eights = !x_axis && !z_axis;  // run-time Y kernels alike
+    if ((x_eights || y_eights || z_axis) && small_pow2) {
         const int best = (c2 + 2) / 3;
         int n8 = 0;
         while ((c2 - 3 * n8 + 1) / 2 + n8 > best) ++n8;
@@ -2211,40 +2224,42 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     p->rset_y = lean(p->ay);
     p->rset_z = lean(p->az);
     // tile width: widest of 4/2/1 whose column tile fits a 72-KB LDS buffer (2 blocks / CU)
-    // Tile shapes.  Defaults measured on MI355X (profiles/): knobs are for re-tuning only.
+    // Tile shapes as measured on MI355X (profiles/).  Rounds 1-3 read them from the environment for tuning sweeps; round 4
+    // made them constants.  What is still read: the ROUTE switches the parity tests compare against each other
+    // (M3D_FFT_XSTATIC / YSTATIC / XREG8 here, M3D_FFT_PRUNE / M3D_RLGC_CHAIN_* in m3d_rlgc.hip).
     auto knob = [](const char *name, int dflt) {
         const char *v = getenv(name);
         return v ? atoi(v) : dflt;
     };
-    p->TW = knob("M3D_FFT_TW", 4);
-    while (p->TW > 1 && (size_t)Yp * p->TW * sizeof(float2) > (size_t)knob("M3D_FFT_YLDS_KB", 72) * 1024) p->TW /= 2;
+    p->TW = 4;
+    while (p->TW > 1 && (size_t)Yp * p->TW * sizeof(float2) > (size_t)72 * 1024) p->TW /= 2;
     p->lds_y = (size_t)Yp * p->TW * sizeof(float2);
     // rows per X block: 4 real rows (2 packed) when they fit 42 KB (2592: 41.5 KB, three workgroups per CU; measured
     // 33.7 -> 31.8 ms per iteration against one packed row per workgroup), else 2
-    p->RB = ((size_t)2 * Xp * sizeof(float2) <= (size_t)knob("M3D_FFT_XLDS_KB", 42) * 1024) ? knob("M3D_FFT_RB", 4) : 2;
+    p->RB = ((size_t)2 * Xp * sizeof(float2) <= (size_t)42 * 1024) ? 4 : 2;
     p->lds_x = (size_t)(p->RB / 2) * Xp * sizeof(float2);
     // the X forward pass re-uses its buffer as a staging area of whole 128-byte spectrum lines (4 rows x TW = 4)
     if (p->TW == 4 && p->RB == 4) p->lds_x = std::max(p->lds_x, (size_t)((Xp / 2 + 1 + 3) / 4) * 128);
-    p->P = knob("M3D_FFT_P", 16);
+    p->P = 16;
     while (p->P > 1 && (size_t)Zp * p->P * sizeof(float2) > 64 * 1024) p->P /= 2;
     p->lds_z = (size_t)Zp * p->P * sizeof(float2);
-    p->xthreads = knob("M3D_FFT_XT", 256);
-    p->gx = knob("M3D_FFT_GX", 4);
-    p->gy = knob("M3D_FFT_GY", 4);
-    p->gz = knob("M3D_FFT_GZ", 4);
-    p->zmirror = knob("M3D_FFT_ZMIRROR", 1) ? 1 : 0;
-    p->zreg = (knob("M3D_FFT_ZREG", 1) && (Zp == 32 || Zp == 64 || Zp == 128 || Zp == 256)) ? Zp / 16 : 0;
-    p->dual_rows = knob("M3D_FFT_DUAL_ROWS", 2);
-    p->dual_threads = knob("M3D_FFT_DUAL_T", 256);
-    p->ythreads = knob("M3D_FFT_YT", 768);
-    p->xcdpair = knob("M3D_FFT_XCDPAIR", 1) ? 1 : 0;
+    p->xthreads = 256;
+    p->gx = 4;
+    p->gy = 4;
+    p->gz = 4;
+    p->zmirror = 1;
+    p->zreg = (Zp == 32 || Zp == 64 || Zp == 128 || Zp == 256) ? Zp / 16 : 0;
+    p->dual_rows = 2;
+    p->dual_threads = 256;
+    p->ythreads = 768;
+    p->xcdpair = 1;
     {   // rows per y chunk of the spectrum layout: a power of two >= 4 (whole X blocks); >= Yp = plain tiled layout
-        int ch = std::max(4, knob("M3D_FFT_CH", 128));
+        const int ch = 128;
         p->lch = 31 - __builtin_clz((unsigned)ch);
         if ((1 << p->lch) >= Yp) p->lch = 30;
     }
-    p->zthreads = std::max(p->P, knob("M3D_FFT_ZT", 128));
-    p->xreg = (knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 9 &&
+    p->zthreads = std::max(p->P, 128);
+    p->xreg = (p->ax.nstages >= 2 && p->ax.radix[0] == 9 &&
                p->ax.radix[p->ax.nstages - 1] == 9 && p->xthreads == 256 && p->dual_threads == 256 &&
                p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && (p->RB / 2) * (Xp / 18 + 1) <= 320 && Xp / 9 <= 320)
                   ? 9 : 0;
@@ -2252,7 +2267,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     if (p->xreg == 9 && (Xp / 9 > 256 || 2 * (Xp / 18 + 1) > 256)) p->xthreads = p->dual_threads = 320;
     // edge radix 8 (factor_23 put an 8 first and last): S = Xp / 8 <= 256 edge items, S / 2 + 1 block pairs per packed
     // row - 2 x 129 at Xp = 2048, so those workgroups take a fifth wave
-    if (!p->xreg && knob("M3D_FFT_XREG", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 8 &&
+    if (!p->xreg && knob("M3D_FFT_XREG8", 1) && p->ax.nstages >= 2 && p->ax.radix[0] == 8 &&
         p->ax.radix[p->ax.nstages - 1] == 8 && p->rset_x == 2 && p->xthreads == 256 && p->dual_threads == 256 &&
         p->dual_rows == 2 && (p->RB == 2 || p->RB == 4) && Xp % 64 == 0 && Xp / 8 <= 256) {
         p->xreg = 8;
@@ -2265,8 +2280,7 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     // their own, with radix-8 stages for the powers of two: the generic kernel runs 2048 as 4 * 4 * 4 * 4 * 4 * 2 - six
     // LDS stages with run-time index arithmetic - and costs 1.55 x per voxel (profiles/r03_sizes.txt).  The Y axis's
     // radix list is private to the Y passes (the spectrum only ever meets the OTF, which the same passes produce).
-    if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && p->TW == 4 && p->lch == 7 && p->gy == 4 &&
-        getenv("M3D_FFT_YT") == nullptr) {
+    if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && p->TW == 4 && p->lch == 7 && p->gy == 4) {
         static const int lists[][5] = {{2048, 8, 8, 8, 4}, {1728, 9, 8, 8, 3}, {1296, 9, 9, 4, 4}, {1152, 9, 8, 4, 4},
                                        {576, 9, 8, 8, 1}};
         for (const auto &l : lists)
@@ -2279,11 +2293,10 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     }
     // the static Y kernels spread (butterfly, column group) items over the threads: 972 (forward) / 486 (inverse) items
     // in the radix-9 stages, one round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
-    if (p->ystatic && getenv("M3D_FFT_YT") == nullptr) p->ythreads = 1024;
+    if (p->ystatic) p->ythreads = 1024;
     // 2592 (2304-pixel sensors): tiles of two columns (41.5 KB, three workgroups per CU), 9 9 8 4, 640 threads - the 576
     // (butterfly, column) items of a radix-9 stage in one round, 3 x 640 threads per CU
-    if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && Yp == 2592 && p->TW == 2 && p->lch == 7 && p->gy == 4 &&
-        getenv("M3D_FFT_YT") == nullptr) {
+    if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && Yp == 2592 && p->TW == 2 && p->lch == 7 && p->gy == 4) {
         static const int l2592[4] = {9, 9, 8, 4};
         p->ystatic = 2592;
         p->ay.nstages = 4;
@@ -2431,7 +2444,7 @@ static int launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, const
         return launch_z(p, spec_b, otf, g, mode, scale, st);
     }
     if (p->zreg) {
-        static const int zp_env = [] { const char *e = getenv("M3D_FFT_ZREG_P"); return e ? atoi(e) : 0; }();  // 256-byte segments: 4 % faster
+        constexpr int zp_env = 0;  // (16 / 32 columns per block were tuning switches of rounds 1-2)
         // columns per block: 512-byte segments (64 columns, 512 threads) are 2-7 % faster than 256-byte ones where the
         // exchange buffer still lets two blocks share a CU (Zp = 128); 16 columns only on request
         const int zp = zp_env == 16 ? 16 : (zp_env == 32 ? 32 : (p->zreg == 8 ? 64 : 32));
@@ -2685,17 +2698,11 @@ int fftconv_to_rows_pair(const FftConvPlan *p, const float *src1, const float *s
     return M3D_OK;
 }
 
-// Static geometry (2187).  The kernel also has run-time geometry builds for every length the register-edge kernels take
-// with four rows per group and tiles of four (M3D_FFT_SPLIT_CHAIN_RT=1): parity green, but measured no faster than the
-// separate kernels there (2048: 18.2 against 17.6 ms per iteration - a fifth wave at 121 registers leaves three
-// workgroups per CU; 1728 / 1296 / 1152: -1 to +1 %; profiles/r03_sizes.txt), so they stay off by default.
-bool fftconv_split_chain_supported(const FftConvPlan *p)
-{
-    if (!p || p->TW != 4 || p->RB != 4) return false;
-    if (p->xstatic) return true;
-    const bool rt = getenv("M3D_FFT_SPLIT_CHAIN_RT") && atoi(getenv("M3D_FFT_SPLIT_CHAIN_RT")) == 1;
-    return rt && ((p->xreg == 9 && p->rset_x == 1) || (p->xreg == 8 && p->rset_x == 2));
-}
+// Static geometry (2187) only.  Round 3 also built the kernel with run-time geometry for every length the register-edge
+// kernels take: parity green and no faster than the separate kernels (2048: 18.2 against 17.6 ms per iteration - a fifth
+// wave at 121 registers leaves three workgroups per CU; 1728 / 1296 / 1152: -1 to +1 %; profiles/r03_sizes.txt).  Those
+// instantiations (and their switch) were taken out in round 4; the kernel keeps its geometry template parameters.
+bool fftconv_split_chain_supported(const FftConvPlan *p) { return p && p->xstatic && p->TW == 4 && p->RB == 4; }
 
 int64_t fftconv_split_chain_blocks(const FftConvPlan *p, const ConvBox *core)
 {
@@ -2713,20 +2720,12 @@ int fftconv_split_chain(const FftConvPlan *p, float2 *spec_hu, float2 *spec_r1, 
         !args->partial || !args->tables.thr)
         return M3D_ERR_INVALID_ARG;
     const ConvGeo g = geo_of(p, nullptr, core);
-    const dim3 grid((unsigned)fftconv_split_chain_blocks(p, core)), block(p->xstatic ? 256 : p->dual_threads);
+    const dim3 grid((unsigned)fftconv_split_chain_blocks(p, core)), block(256);
     const size_t lds = (size_t)2 * p->Xp * sizeof(float2);
 #define M3D_LAUNCH_SC(T, NS, R, RS) \
     hipLaunchKernelGGL((k_x_inverse_split_chain<T, NS, R, RS>), grid, block, lds, st, spec_hu, spec_r1, g, p->ax, *args)
-    if (p->xstatic) {
-        if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 2187, 9, 1);
-        else M3D_LAUNCH_SC(float, 2187, 9, 1);
-    } else if (p->xreg == 8) {
-        if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 0, 8, 2);
-        else M3D_LAUNCH_SC(float, 0, 8, 2);
-    } else {
-        if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 0, 9, 1);
-        else M3D_LAUNCH_SC(float, 0, 9, 1);
-    }
+    if (args->image_is_u16) M3D_LAUNCH_SC(uint16_t, 2187, 9, 1);
+    else M3D_LAUNCH_SC(float, 2187, 9, 1);
 #undef M3D_LAUNCH_SC
     if (log && log->mark(EventLog::kXI)) return M3D_ERR_HIP;
     M3D_KERNEL_CHECK();

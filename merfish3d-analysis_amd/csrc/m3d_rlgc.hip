@@ -207,23 +207,16 @@ __global__ void k_cmul(float2 *__restrict__ x, const float2 *__restrict__ h, int
     }
 }
 
-// the iteration counter of the graph-replayed solver loop (m3d_rlgc_run)
-__global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
-__global__ void k_inc_u32(uint32_t *p) { *p += 1u; }
-
 // ---------------------------------------------------------------- iteration kernels
 // rlgc.py:619-628 + 654-672 (core region): split, KL partial sums, both ratio volumes.
 template <typename T>
 __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict__ image,
                               float *__restrict__ r1, float *__restrict__ r2, Geo g,
-                              uint32_t iteration_arg, uint64_t seed, BinomTables tables,
-                              const float *__restrict__ injected, KlPartial *__restrict__ partial,
-                              const uint32_t *__restrict__ iteration_dev = nullptr)
+                              uint32_t iteration, uint64_t seed, BinomTables tables,
+                              const float *__restrict__ injected, KlPartial *__restrict__ partial)
 {
     __shared__ double sm[4];
     const float eps = 1e-4f;
-    // (an iteration replayed from a hipGraph reads its number from device memory, see m3d_rlgc_run)
-    const uint32_t iteration = iteration_dev ? *iteration_dev : iteration_arg;
     // per-thread partial sums in float32 (<= a few hundred terms each), promoted to double
     // for the cross-thread reduction: keeps the kernel HBM-bound instead of f64-VALU-bound
     float A = 0, Bim = 0, B1 = 0, B2 = 0, Tim = 0, T1 = 0, T2 = 0;
@@ -633,11 +626,6 @@ struct m3d_rlgc_plan {
     void *setup_workspace = nullptr;
     unsigned long long setup_psf_hash = 0;
     int setup_normalize = -1;
-    // graph-replayed solver loop (launch-bound volumes): a capturable stream of the plan's own, the event that orders it
-    // behind the caller's stream, the device-side iteration counter
-    hipStream_t gstream = nullptr;
-    hipEvent_t gev = nullptr;
-    uint32_t *iter_dev = nullptr;
 };
 
 #define M3D_ROCFFT_CHECK(expr)                                   \
@@ -805,9 +793,7 @@ int m3d_rlgc_plan_create(const int32_t image_zyx[3], const int32_t psf_zyx[3], i
     p->o_r2 = take(fb);
     p->o_w1 = take(fb);
     p->o_w2 = take(fb > cb ? fb : cb);  // doubles as the second scratch spectrum of the dual X inverse pass
-    if (p->fc && m3d::fftconv_real_otf_supported(p->fc) &&
-        !(getenv("M3D_RLGC_REAL_OTF2") && atoi(getenv("M3D_RLGC_REAL_OTF2")) == 0))
-        p->o_otf2 = take(cb / 2);
+    if (p->fc && m3d::fftconv_real_otf_supported(p->fc)) p->o_otf2 = take(cb / 2);
     p->o_part = take(sizeof(KlPartial) * (size_t)(kRowGrid + kMaxGrid) * 2);
     p->o_status = take(sizeof(Status));
     p->o_fftwork = take(p->fft_work ? p->fft_work : 256);
@@ -837,9 +823,6 @@ int m3d_rlgc_plan_destroy(m3d_rlgc_plan *p)
     for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->loop_ev)
         if (e) (void)hipEventDestroy(e);
-    if (p->gev) (void)hipEventDestroy(p->gev);
-    if (p->gstream) (void)hipStreamDestroy(p->gstream);
-    if (p->iter_dev) (void)hipFree(p->iter_dev);
     delete p;
     return M3D_OK;
 }
@@ -858,27 +841,9 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     hipStream_t st = (hipStream_t)stream_v;
     BinomTables binom;
     if (int rc_tables = device_binom_tables(&binom)) return rc_tables;
-    // The solver iteration can be replayed from a hipGraph (M3D_RLGC_GRAPH=1): [update, next forward model + KL] is
-    // captured once per parity of the estimate's two buffers and launched as one unit; the stop test's read-back stays
-    // outside.  Capture needs a stream of its own (the caller's may be the legacy default stream): the plan's stream
-    // waits for the caller's work, and the call ends with a synchronisation as before.  Off by default: measured on
-    // MI355X / ROCm 7.2 (scripts/gpu_probe_graph.py, profiles/r03_graph_replay.txt) the replay is bit-equal and no
-    // faster at any size - 0.389 against 0.374 ms per iteration on the launch-bound 16 x 256 x 256 tile, whose kernels
-    // need 0.2 ms: what a launch-bound iteration waits for is the dispatch latency between dependent kernels and the
-    // read-back round trip, neither of which a graph removes; the host was already enqueueing ahead of the device.
-    bool use_graph = false;
-    if (p->fc && !injected && (params->profile & 1) == 0) {
-        const char *gk = getenv("M3D_RLGC_GRAPH");
-        use_graph = gk && atoi(gk) != 0;
-    }
-    if (use_graph) {
-        if (!p->gstream) M3D_HIP_CHECK(hipStreamCreateWithFlags(&p->gstream, hipStreamNonBlocking));
-        if (!p->gev) M3D_HIP_CHECK(hipEventCreateWithFlags(&p->gev, hipEventDisableTiming));
-        if (!p->iter_dev) M3D_HIP_CHECK(hipMalloc((void **)&p->iter_dev, sizeof(uint32_t)));
-        M3D_HIP_CHECK(hipEventRecord(p->gev, st));
-        M3D_HIP_CHECK(hipStreamWaitEvent(p->gstream, p->gev, 0));
-        st = p->gstream;
-    }
+    // (Round 3 could replay the loop body from hipGraphs - bit-equal and measured no faster at any size on MI355X / ROCm 7.2,
+    // profiles/r03_graph_replay.txt: a launch-bound iteration waits for the dispatch latency between dependent kernels and
+    // the stop test's read-back, neither of which a graph removes.  The path was taken out in round 4.)
     const Geo g = p->g;
     char *ws = (char *)workspace;
     float2 *otf = (float2 *)(ws + p->o_otf);
@@ -1051,7 +1016,6 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         M3D_HIP_CHECK(hipMemsetAsync(r1, 0, sizeof(float) * (size_t)g.Np, st));
         M3D_HIP_CHECK(hipMemsetAsync(r2, 0, sizeof(float) * (size_t)g.Np, st));
     }
-    const uint32_t *it_dev = nullptr;  // set while an iteration is being captured into a graph (see run_body)
     auto enqueue_forward = [&](int it) -> int {
         const float *inj =
             (injected && it < n_injected) ? injected + (size_t)it * (size_t)g.N : nullptr;
@@ -1068,7 +1032,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             }
             KlPartial *big = (KlPartial *)r1;
             const m3d::SplitArgs sa = {image, image_dtype == M3D_U16 ? 1 : 0, inj, (uint32_t)it, params->seed, binom,
-                                       (m3d::SplitPartial *)big, it_dev};
+                                       (m3d::SplitPartial *)big};
             if ((rc3 = m3d::fftconv_split_chain(p->fc, cbuf2, cbuf, &core, &sa, st, &elog))) return rc3;
             hipLaunchKernelGGL(k_kl_reduce, dim3(128), dim3(kBlock), 0, st, big,
                                (int)m3d::fftconv_split_chain_blocks(p->fc, &core), kl_part);
@@ -1082,11 +1046,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
         if (image_dtype == M3D_U16)
             hipLaunchKernelGGL(k_split_ratio<uint16_t>, dim3(g_core), rb, 0, st, hu,
                                (const uint16_t *)image, r1, r2, g, (uint32_t)it, params->seed,
-                               binom, inj, kl_part, it_dev);
+                               binom, inj, kl_part);
         else
             hipLaunchKernelGGL(k_split_ratio<float>, dim3(g_core), rb, 0, st, hu,
                                (const float *)image, r1, r2, g, (uint32_t)it, params->seed, binom,
-                               inj, kl_part, it_dev);
+                               inj, kl_part);
         hipLaunchKernelGGL(k_kl_finalize, dim3(1), dim3(kBlock), 0, st, kl_part, g_core, dstat);
         M3D_KERNEL_CHECK();
         return M3D_OK;
@@ -1102,7 +1066,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             float2 *cbuf2 = (float2 *)w2;  // w2 itself is never materialised on this path
             const m3d::ConvBox *in = &core;
             elog.convolutions += 2;
-            static const bool zpair = !(getenv("M3D_RLGC_NO_ZPAIR") && atoi(getenv("M3D_RLGC_NO_ZPAIR")));
+            constexpr bool zpair = true;  // (the two single launches remain for plans without the paired Z pass)
             if (split_chain) {  // cbuf / cbuf2 hold the rows' X transforms of ratio1 / ratio2 already
                 if ((rc2 = m3d::fftconv_to_rows_pair(p->fc, nullptr, nullptr, otf, 1, cbuf, cbuf2, st, &elog, in, true)))
                     return rc2;
@@ -1113,7 +1077,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
                 if ((rc2 = m3d::fftconv_to_rows(p->fc, r2, otf, 1, cbuf2, st, &elog, in, nullptr, nullptr))) return rc2;
             }
             // ... and the consensus input goes straight into the X forward transform of its own convolution
-            const bool chain = !(getenv("M3D_RLGC_NO_CHAIN") && atoi(getenv("M3D_RLGC_NO_CHAIN")));
+            constexpr bool chain = true;
             const m3d::ConvEpilogue e1 = {m3d::ConvEpilogue::kConsensus, nullptr, un, hu, w1, cons_red, core};
             if ((rc2 = m3d::fftconv_dual_consensus(p->fc, cbuf, cbuf2, st, &elog, &e1, chain))) return rc2;
             m3d::ConvEpilogue e2 = {m3d::ConvEpilogue::kUpdate, recon_cur, w1, recon_prev, nullptr, upd_red, core};
@@ -1143,52 +1107,11 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     };
     auto kl_from = [](double T, double A, double B) { return T / A - std::log(A) + std::log(B); };
     // One loop body = the update of iteration k, the swap of the estimate's two buffers, the forward model + KL sums of
-    // iteration k + 1.  Graph mode: captured the first time each buffer parity comes up, replayed afterwards; the
-    // iteration number of the photon split then comes from p->iter_dev, advanced by the graph's last node.
-    struct GraphPair {
-        hipGraphExec_t exec[2] = {nullptr, nullptr};
-        ~GraphPair()
-        {
-            for (hipGraphExec_t e : exec)
-                if (e) (void)hipGraphExecDestroy(e);
-        }
-    } graphs;
-    int bodies = 0;
+    // iteration k + 1 (enqueued speculatively: a stop costs one wasted convolution).
     auto run_body = [&](int it_next) -> int {
-        if (!use_graph) {
-            if (int rc2 = enqueue_update()) return rc2;
-            std::swap(recon_cur, recon_prev);  // recon_prev held the updated volume; swap roles
-            return enqueue_forward(it_next);   // speculative next Hu + KL
-        }
-        const int par = bodies++ & 1;
-        if (!graphs.exec[par]) {
-            hipGraph_t gr = nullptr;
-            M3D_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            it_dev = p->iter_dev;
-            int rc2 = enqueue_update();
-            std::swap(recon_cur, recon_prev);
-            if (!rc2) rc2 = enqueue_forward(it_next);
-            hipLaunchKernelGGL(k_inc_u32, dim3(1), dim3(1), 0, st, p->iter_dev);
-            it_dev = nullptr;
-            const hipError_t ce = hipStreamEndCapture(st, &gr);  // (always: the stream must leave capture mode)
-            if (rc2 || ce != hipSuccess || !gr) {
-                if (gr) (void)hipGraphDestroy(gr);
-                if (!rc2) set_err("hipStreamEndCapture", hipGetErrorString(ce));
-                return rc2 ? rc2 : M3D_ERR_HIP;
-            }
-            const hipError_t ie = hipGraphInstantiate(&graphs.exec[par], gr, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(gr);
-            if (ie != hipSuccess) {
-                set_err("hipGraphInstantiate", hipGetErrorString(ie));
-                return M3D_ERR_HIP;
-            }
-        } else {  // what the two enqueue calls do on the host
-            std::swap(recon_cur, recon_prev);
-            hu_x_ready = false;
-            elog.convolutions += 4;
-        }
-        M3D_HIP_CHECK(hipGraphLaunch(graphs.exec[par], st));
-        return M3D_OK;
+        if (int rc2 = enqueue_update()) return rc2;
+        std::swap(recon_cur, recon_prev);  // recon_prev held the updated volume; swap roles
+        return enqueue_forward(it_next);   // speculative next Hu + KL
     };
 
     if (res) {
@@ -1205,7 +1128,6 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
             if (!e) M3D_HIP_CHECK(hipEventCreate(&e));
         M3D_HIP_CHECK(hipEventRecord(p->loop_ev[0], st));
     }
-    if (use_graph) hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, p->iter_dev, 1u);
     if ((rc = enqueue_forward(0))) return rc;
     if ((rc = read_status())) return rc;
     for (;;) {

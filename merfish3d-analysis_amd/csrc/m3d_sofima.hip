@@ -1192,7 +1192,7 @@ int m3d_subpixel_refine(const float *pre, const float *post, const int32_t shape
         return M3D_ERR_UNSUPPORTED;
     }
     // three offsets over a three-point window: the one-pass kernel (window only in LDS: two workgroups per CU)
-    static const bool one_pass_ok = !(getenv("M3D_SUBPIXEL_ONE_PASS") && atoi(getenv("M3D_SUBPIXEL_ONE_PASS")) == 0);
+    constexpr bool one_pass_ok = true;
     const size_t win_bytes = sizeof(float) * (size_t)A.region.z * A.region.y * A.region.x;
     if (one_pass_ok && n_offsets == 3 && extra == 3 && 
         offsets_host[0] <= offsets_host[1] && offsets_host[1] <= offsets_host[2]) {

@@ -79,6 +79,16 @@ class InMemoryDataStore:
                     if rows.size:
                         self._round_linker[(tile, bit_id)] = int(order[rows[0], 0])
 
+    def load_codebook_parsed(self):
+        """``(gene_ids, codebook_matrix)`` (qi2labDataStore.py:2841-2868; the simulation scorer's CLI reads it,
+        cli/statphysbio_simulation/calculate_F1.py:230)."""
+        try:
+            gene_ids = self.codebook.iloc[:, 0].tolist()
+            return gene_ids, self.codebook.iloc[:, 1:].to_numpy().astype(int)
+        except (AttributeError, KeyError, ValueError, TypeError):
+            print("Error parsing codebook.")
+            return None
+
     # ---- id helpers (qi2labDataStore.py:2501-2515) ------------------------------------
     @property
     def num_tiles(self):
@@ -180,7 +190,9 @@ class InMemoryDataStore:
 
     def load_local_fiducial_image(self, tile, round, return_future=True):
         k = self._key(tile, round=round)
-        arr = self._fiducial_decon.get(k, self._corrected.get(k))
+        arr = self._fiducial_decon.get(k)
+        if arr is None:      # (not ``get(k, fallback)``: on a disk store the fallback would be READ before it is needed)
+            arr = self._corrected.get(k)
         return None if arr is None else self._out(arr, return_future)
 
     def save_local_deconvolved_readout_image(self, image, tile, bit, **_):
@@ -189,7 +201,9 @@ class InMemoryDataStore:
     def load_local_readout_image(self, tile, bit, return_future=True):
         """Deconvolved readout if present else corrected (qi2labDataStore.py:4709)."""
         k = self._key(tile, bit=bit)
-        arr = self._readout_decon.get(k, self._corrected.get(k))
+        arr = self._readout_decon.get(k)
+        if arr is None:
+            arr = self._corrected.get(k)
         return None if arr is None else self._out(arr, return_future)
 
     def save_local_feature_predictor_image(self, feature_predictor_image, tile, bit, **_):
@@ -302,24 +316,39 @@ class _DiskImages:
     def __contains__(self, key) -> bool:
         from . import zarr_io
 
-        return key is not None and (zarr_io.image_store_path(self.path(key)) / "0" / "zarr.json").exists()
+        if key is None:
+            return False
+        path = self.path(key)
+        if path in self._owner._resident or path in self._owner._pending_writes:
+            return True
+        return (zarr_io.image_store_path(path) / "0" / "zarr.json").exists()
 
     def __setitem__(self, key, image) -> None:
-        spacing = self._owner.voxel_size_zyx_um
         self._owner._drop_prefetched(self.path(key))
-        self._owner._io.write_image(self.path(key), image, ome_scale=spacing)
+        self._owner._write(self.path(key), image)
 
     def __getitem__(self, key):
-        ready = self._owner._take_prefetched(self.path(key))
+        path = self.path(key)
+        kept = self._owner._resident.get(path)
+        if kept is not None:                       # written by this process and still in HBM: no I/O
+            return kept
+        ready = self._owner._take_prefetched(path)
         if ready is not None:
             return ready
-        return self._owner._io.read_image(self.path(key), device=self._owner._device)
+        self._owner._wait_for_write(path)          # queued behind the compute: let it land first
+        return self._owner._io.read_image(path, device=self._owner._device)
 
     def get(self, key, default=None):
         return self[key] if key in self else default
 
     def shape(self, key):
-        return self._owner._io.image_shape(self.path(key)) if key in self else None
+        if key is None or key not in self:
+            return None
+        kept = self._owner._resident.get(self.path(key))
+        if kept is not None:
+            return tuple(int(v) for v in kept.shape)
+        self._owner._wait_for_write(self.path(key))
+        return self._owner._io.image_shape(self.path(key))
 
 
 class ZarrImageDataStore(InMemoryDataStore):
@@ -332,7 +361,14 @@ class ZarrImageDataStore(InMemoryDataStore):
     tables stay in memory: the reference's JSON / parquet sidecars are outside the hot path.
     """
 
-    def __init__(self, datastore_path, *, device=None, num_threads=None, **kwargs):
+    def __init__(self, datastore_path, *, device=None, num_threads=None, write_behind: bool = False,
+                 prefetch_threads: int | None = None, write_threads: int | None = None,
+                 max_pending_writes: int = 6, **kwargs):
+        """``write_behind=True`` (needs ``device``): image saves return at once - the volume is handed to a
+        background writer with its own HIP stream and zstd threads and stays readable from HBM (``_resident``)
+        until ``evict_tile`` - so a tile's I/O runs under its own and the next tile's kernels.  ``flush()`` waits for
+        the queue; a load of an image whose write is still queued waits for that write only.  The reference writes
+        synchronously (qi2labDataStore.py:2273-2373); results on disk are byte-identical either way."""
         from . import zarr_io
 
         super().__init__(datastore_path=datastore_path, **kwargs)
@@ -342,6 +378,17 @@ class ZarrImageDataStore(InMemoryDataStore):
         self._prefetch_pool = None
         self._prefetch_io = None
         self._prefetch_stream = None
+        self._prefetch_threads = prefetch_threads
+        self._write_behind = bool(write_behind) and device is not None
+        self._write_threads = write_threads
+        self._max_pending_writes = int(max_pending_writes)
+        self._resident = {}          # image path -> tensor in HBM written through this store (write-behind only)
+        self._pending_writes = {}    # image path -> Future of the background write
+        self._write_pool = None
+        self._write_io = None
+        self._write_stream = None
+        self.io_seconds = {"read_wait": 0.0, "write_wait": 0.0}   # *_wait: time the CALLER spent waiting on I/O;
+        self.io_counts = {}                                        # *_busy: time the background threads spent in it
         self.fiducial_folder_name = "fiducial"
         self._fiducial_root_path = self._datastore_path / self.fiducial_folder_name
         self._readouts_root_path = self._datastore_path / "readouts"
@@ -359,9 +406,13 @@ class ZarrImageDataStore(InMemoryDataStore):
     def __getstate__(self):
         state = dict(self.__dict__)
         state["_io_threads"] = self._io.num_threads
-        for key in ("_io", "_prefetch_pool", "_prefetch_io", "_prefetch_stream"):
+        self.flush()
+        for key in ("_io", "_prefetch_pool", "_prefetch_io", "_prefetch_stream", "_write_pool", "_write_io",
+                    "_write_stream"):
             state[key] = None
         state["_prefetched"] = {}
+        state["_resident"] = {}
+        state["_pending_writes"] = {}
         return state
 
     def __setstate__(self, state):
@@ -377,6 +428,10 @@ class ZarrImageDataStore(InMemoryDataStore):
         if round is None and bit is None:
             from . import zarr_io
 
+            kept = self._resident.get(Path(tile))
+            if kept is not None:
+                return tuple(int(v) for v in kept.shape)
+            self._wait_for_write(Path(tile))
             path = zarr_io.image_store_path(tile)
             return self._io.image_shape(path) if (path / "0" / "zarr.json").exists() else None
         k = self._key(tile, round, bit)
@@ -416,16 +471,60 @@ class ZarrImageDataStore(InMemoryDataStore):
                     queued += 1
         return queued
 
+    def prefetch_tile_inputs(self, tile, rounds=None, bits=None) -> int:
+        """Read-ahead for the PREPROCESS of ``tile`` (DataRegistration.py:390-453, 906-1121): the corrected fiducial
+        image of every round, then per bit the corrected readout and the predictor image (if one is stored), queued
+        in the order the operators ask for them.  Returns the number of loads queued."""
+        if self._device is None:
+            return 0
+        t = self._tile(tile)
+        paths = []
+        for rnd in (self.round_ids if rounds is None else rounds):
+            k = self._key(t, round=rnd)
+            if k is not None and k in self._corrected:
+                paths.append(self._corrected.path(k))
+        for bit in (self.bit_ids if bits is None else bits):
+            k = self._key(t, bit=bit)
+            if k is None:
+                continue
+            for family in (self._corrected, self._predictor):
+                if k in family:
+                    paths.append(family.path(k))
+        return self.prefetch_images(paths)
+
+    def prefetch_images(self, paths) -> int:
+        from concurrent.futures import ThreadPoolExecutor
+
+        if self._device is None:
+            return 0
+        if self._prefetch_pool is None:
+            self._prefetch_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="m3d-prefetch")
+        queued = 0
+        for path in paths:
+            if path not in self._prefetched and path not in self._resident:
+                self._prefetched[path] = self._prefetch_pool.submit(self._prefetch_one, path)
+                queued += 1
+        return queued
+
     def _prefetch_one(self, path):
         import torch
 
         from . import zarr_io
 
+        self._wait_for_write(path, account=False)
         if self._prefetch_io is None:
-            self._prefetch_io = zarr_io.ImageIO(num_threads=self._io.num_threads)
+            self._prefetch_io = zarr_io.ImageIO(num_threads=self._prefetch_threads or self._io.num_threads)
             self._prefetch_stream = torch.cuda.Stream(device=self._device)
+        import time
+
+        t0 = time.perf_counter()
         with torch.cuda.stream(self._prefetch_stream):
-            return self._prefetch_io.read_image(path, device=self._device)   # returns after its stream drained
+            out = self._prefetch_io.read_image(path, device=self._device)   # returns after its stream drained
+        st = self._prefetch_io.last_stats
+        self.io_seconds["read_busy"] = self.io_seconds.get("read_busy", 0.0) + time.perf_counter() - t0
+        self.io_counts["images_read"] = self.io_counts.get("images_read", 0) + 1
+        self.io_counts["raw_bytes_read"] = self.io_counts.get("raw_bytes_read", 0) + int(st.get("raw_bytes", 0))
+        return out
 
     def _take_prefetched(self, path):
         fut = self._prefetched.pop(path, None)
@@ -433,9 +532,102 @@ class ZarrImageDataStore(InMemoryDataStore):
             return None
         import torch
 
+        import time
+
+        t0 = time.perf_counter()
         tensor = fut.result()
+        self.io_seconds["read_wait"] += time.perf_counter() - t0
         tensor.record_stream(torch.cuda.current_stream(tensor.device))  # allocated under the side stream
         return tensor
+
+    # ---- write-behind: saves are queued to a background writer, the volume stays readable from HBM ----
+    def _write(self, path, image) -> None:
+        import torch
+
+        spacing = self.voxel_size_zyx_um
+        if not (self._write_behind and isinstance(image, torch.Tensor) and image.is_cuda):
+            self._wait_for_write(path)
+            self._resident.pop(path, None)
+            self._io.write_image(path, image, ome_scale=spacing)
+            return
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+
+        if self._write_pool is None:
+            self._write_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="m3d-writer")
+        self._wait_for_write(path)                       # an older version of the same image goes first
+        t0 = time.perf_counter()
+        while len(self._pending_writes) >= self._max_pending_writes:   # back-pressure: bounded HBM held by the queue
+            oldest = next(iter(self._pending_writes))
+            self._pending_writes.pop(oldest).result()
+        self.io_seconds["write_wait"] += time.perf_counter() - t0
+        image = image.contiguous()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(image.device))         # the producer's kernels, as enqueued so far
+        self._resident[path] = image
+        self._pending_writes[path] = self._write_pool.submit(self._write_one, path, image, ready, spacing)
+
+    def _write_one(self, path, image, ready, spacing):
+        import torch
+
+        from . import zarr_io
+
+        if self._write_io is None:
+            self._write_io = zarr_io.ImageIO(num_threads=self._write_threads or self._io.num_threads)
+            self._write_stream = torch.cuda.Stream(device=self._device)
+        import time
+
+        t0 = time.perf_counter()
+        with torch.cuda.device(image.device), torch.cuda.stream(self._write_stream):
+            self._write_stream.wait_event(ready)
+            ready.synchronize()          # (not part of the write: the producer may still be computing this volume)
+            t1 = time.perf_counter()
+            self._write_io.write_image(path, image, ome_scale=spacing)   # returns when the last chunk is on disk
+        st = self._write_io.last_stats
+        self.io_seconds["write_busy"] = self.io_seconds.get("write_busy", 0.0) + time.perf_counter() - t1
+        self.io_seconds["write_entropy"] = self.io_seconds.get("write_entropy", 0.0) + float(st.get("seconds_entropy", 0.0))
+        self.io_seconds["write_producer_wait"] = self.io_seconds.get("write_producer_wait", 0.0) + t1 - t0
+        self.io_counts["images_written"] = self.io_counts.get("images_written", 0) + 1
+        self.io_counts["raw_bytes_written"] = self.io_counts.get("raw_bytes_written", 0) + int(st.get("raw_bytes", 0))
+        self.io_counts["file_bytes_written"] = self.io_counts.get("file_bytes_written", 0) + int(st.get("file_bytes", 0))
+        return path
+
+    def _wait_for_write(self, path, account: bool = True) -> None:
+        fut = self._pending_writes.get(path)
+        if fut is None:
+            return
+        import time
+
+        t0 = time.perf_counter()
+        fut.result()
+        self._pending_writes.pop(path, None)
+        if account:
+            self.io_seconds["write_wait"] += time.perf_counter() - t0
+
+    def flush(self) -> None:
+        """Wait until every queued image write is on disk (errors of the background writer surface here)."""
+        import time
+
+        t0 = time.perf_counter()
+        for path in list(self._pending_writes):
+            fut = self._pending_writes.pop(path, None)
+            if fut is not None:
+                fut.result()
+        self.io_seconds["write_wait"] += time.perf_counter() - t0
+
+    def evict_tile(self, tile) -> int:
+        """Drop the HBM copies this store kept of ``tile``'s written images (queued writes keep their own
+        reference until they are on disk) and any read-ahead that was not consumed; returns the number dropped."""
+        t = self._tile(tile)
+        if t is None:
+            return 0
+        n = 0
+        for path in [p for p in self._resident if p.parent.parent.name == t]:
+            del self._resident[path]
+            n += 1
+        for path in [p for p in self._prefetched if p.parent.parent.name == t]:
+            self._drop_prefetched(path)
+        return n
 
     def _drop_prefetched(self, path) -> None:
         fut = self._prefetched.pop(path, None)

@@ -48,7 +48,8 @@ def _jsonable(value: Any) -> Any:
 class Qi2labDiskStore(ZarrImageDataStore):
     in_memory = False
 
-    def __init__(self, datastore_path, *, device=None, num_threads=None, **create):
+    def __init__(self, datastore_path, *, device=None, num_threads=None, write_behind=False, prefetch_threads=None,
+                 write_threads=None, max_pending_writes=6, **create):
         """Open ``datastore_path`` if it holds ``calibrations/attributes.json``; otherwise create it from
         ``create`` = ``num_tiles, num_rounds, num_bits, codebook`` (DataFrame: gene_id + one column per bit)
         [, ``voxel_size_zyx_um``, ``microscope_type``, ``experiment_order`` (rows: fiducial round, bits),
@@ -72,7 +73,9 @@ class Qi2labDiskStore(ZarrImageDataStore):
             kwargs = {k: create.pop(k) for k in ("num_tiles", "num_rounds", "num_bits", "codebook")}
             kwargs["voxel_size_zyx_um"] = create.pop("voxel_size_zyx_um", (0.315, 0.098, 0.098))
             kwargs["microscope_type"] = create.pop("microscope_type", "3D")
-        super().__init__(root, device=device, num_threads=num_threads, **kwargs)
+        super().__init__(root, device=device, num_threads=num_threads, write_behind=write_behind,
+                         prefetch_threads=prefetch_threads, write_threads=write_threads,
+                         max_pending_writes=max_pending_writes, **kwargs)
         self._attr_cache = {}
         self._calibrations_zarr_path = root / "calibrations"
         self._decoded_root_path = root / "decoded"

@@ -19,7 +19,6 @@ NumPy volumes in -> NumPy field out; torch tensors already in HBM are used in pl
 
 from __future__ import annotations
 
-import os
 from dataclasses import asdict, dataclass
 from typing import Any
 
@@ -30,8 +29,8 @@ _CAP_UPSCALE = 10.0
 _PEAK_THRESHOLD_REL = 0.5
 # nodes per rocFFT batch: 1024 x (20 x 64 x 64) complex64 = 640 MiB of HBM
 _XCORR_NODES_PER_BATCH = 1024
-_XCORR_FUSED = os.environ.get("M3D_SOFIMA_FUSED_XCORR", "1") != "0"
-_XCORR_FUSED_NODES_PER_BATCH = int(os.environ.get("M3D_SOFIMA_FUSED_BATCH", "2048"))  # 2.4 GiB of scratch; flat from 1024 up
+_XCORR_FUSED = True   # module attribute, not an environment switch: the parity test flips it to reach the rocFFT route
+_XCORR_FUSED_NODES_PER_BATCH = 2048  # 2.4 GiB of scratch; flat from 1024 up
 
 
 @dataclass(frozen=True)

@@ -328,3 +328,87 @@ def hip_pipeline_score(store, gt, radius: float, deformable: bool, decode_kw: di
     dec.optimize_normalization_by_decoding(n_random_tiles=1, n_iterations=3, **decode_kw)
     dec.decode_all_tiles(assign_to_cells=False, normalization_method="iterative", **decode_kw)
     return {**sim.calculate_F1(store, gt, search_radius=radius), **_details(store, dec)}
+
+
+def hip_readouts_then_score(store, gt, transforms_zyx_um, radius: float, decode_kw: dict,
+                            reference_stream: bool = False) -> dict:
+    """The HIP pipeline downstream of GIVEN round transforms (tests/test_gpu_f1_reference_run.py): readout
+    deconvolution (``utils.rlgc`` in the call form of DataRegistration.py:379-387, clip -> uint16), the shared predictor
+    stand-in, then ``PixelDecoder`` (optimise normalisation, decode all tiles, blank-fraction filter) and the scorer.
+
+    ``reference_stream``: the photon splits of every iteration are the ones the reference run drew (NumPy's
+    ``default_rng(42).binomial``, replayed by the oracle in spawned worker processes and handed to the HIP solver through
+    its injection hook) instead of the build's Philox stream - the two pipelines then differ by float rounding only.
+    Returns the scorer's dictionary plus ``uint16_flips`` (fraction of deconvolved voxels that differ from the replay's,
+    reference_stream only)."""
+    import torch
+
+    sim, PD, rl = pkg("simulation"), pkg("PixelDecoder"), pkg("utils.rlgc")
+    t = store.tile_ids[0]
+    psfs = store.channel_psfs
+    for rid, T in zip(store.round_ids, transforms_zyx_um):
+        store.save_local_round_transform_zyx_um(np.asarray(T, dtype=np.float32), tile=t, round=rid)
+    raws, bit_psfs = [], []
+    for bit_id in store.bit_ids:
+        ex, _em = store.load_local_wavelengths_um(tile=t, bit=bit_id)
+        raws.append(np.asarray(store.load_local_corrected_image(tile=t, bit=bit_id, return_future=False)))
+        bit_psfs.append(np.asarray(psfs[1 if ex < 0.600 else 2], dtype=np.float32))
+    replays = None
+    if reference_stream:
+        import multiprocessing as mp
+        import os
+        from concurrent.futures import ProcessPoolExecutor
+
+        from oracle_workers import rlgc_reference_stream
+
+        n_proc = max(1, min(8, (os.cpu_count() or 2) // 2))
+        with ProcessPoolExecutor(n_proc, mp_context=mp.get_context("spawn")) as pool:   # children never touch the GPU
+            replays = list(pool.map(rlgc_reference_stream, [(raws[b], bit_psfs[b], 42, 2) for b in range(len(raws))]))
+    flips = total = 0
+    for b, bit_id in enumerate(store.bit_ids):
+        if replays is None:
+            out = rl.chunked_rlgc(image=raws[b], psf=bit_psfs[b], gpu_id=0, crop_yx=2048, crop_z=None,
+                                  release_memory=False)
+        else:
+            ref, r_iters, r_stop, splits = replays[b]
+            o, info = rl.rlgc_device(torch.from_numpy(raws[b]).to("cuda:0"), torch.from_numpy(bit_psfs[b]).to("cuda:0"),
+                                     injected_splits=torch.from_numpy(splits.astype(np.float32)).to("cuda:0"))
+            assert (info.iterations, info.stop_reason) == (r_iters, r_stop), (bit_id, info.iterations, info.stop_reason,
+                                                                               r_iters, r_stop)
+            out = o.cpu().numpy()
+            d = np.abs(np.clip(out, 0, 65535).astype(np.uint16).astype(np.int64)
+                       - np.clip(ref, 0, 65535).astype(np.uint16).astype(np.int64))
+            assert d.max() <= 1, (bit_id, int(d.max()))
+            flips += int((d > 0).sum())
+            total += d.size
+        decon = np.clip(out, 0, 65535).astype(np.uint16)
+        store.save_local_deconvolved_readout_image(decon, tile=t, bit=bit_id)
+        _spots, prob = predictor(decon)
+        store.save_local_feature_predictor_image(prob, tile=t, bit=bit_id)
+    dec = PD.PixelDecoder(store, merfish_bits=16, num_gpus=1, verbose=0)
+    dec.optimize_normalization_by_decoding(n_random_tiles=1, n_iterations=3, **decode_kw)
+    dec.decode_all_tiles(assign_to_cells=False, normalization_method="iterative", **decode_kw)
+    res = {**sim.calculate_F1(store, gt, search_radius=radius), **_details(store, dec)}
+    if total:
+        res["uint16_flips"] = flips / total
+    return res
+
+
+def oracle_readouts_then_score(store, gt, transforms_zyx_um, radius: float, decode_kw: dict, fft_workers: int = 8) -> dict:
+    """The ORACLE pipeline downstream of given round transforms (the twin of ``hip_readouts_then_score``)."""
+    t = store.tile_ids[0]
+    psfs = store.channel_psfs
+    for rid, T in zip(store.round_ids, transforms_zyx_um):
+        store.save_local_round_transform_zyx_um(np.asarray(T, dtype=np.float32), tile=t, round=rid)
+    rlgc_ref.FFT_WORKERS = fft_workers
+    try:
+        for bit_id in store.bit_ids:
+            ex, _em = store.load_local_wavelengths_um(tile=t, bit=bit_id)
+            raw = store.load_local_corrected_image(tile=t, bit=bit_id, return_future=False)
+            decon = _decon_u16(raw, psfs[1 if ex < 0.600 else 2])
+            store.save_local_deconvolved_readout_image(decon, tile=t, bit=bit_id)
+            _spots, prob = predictor(decon)
+            store.save_local_feature_predictor_image(prob, tile=t, bit=bit_id)
+    finally:
+        rlgc_ref.FFT_WORKERS = 0
+    return oracle_decode_and_score(store, gt, radius, decode_kw)

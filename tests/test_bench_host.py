@@ -71,3 +71,22 @@ def test_product_path_never_touches_the_oracle():
             if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
                 importers.add(getattr(fn, "name", "<module>"))
     assert importers <= {"cpu_baseline"}, importers
+
+
+def test_visible_gpu_count_takes_the_smallest_claim_and_admits_ignorance(monkeypatch):
+    """several visibility variables -> the smallest list counts; no list and no readable KFD
+    topology -> None (the launcher then skips its pre-check instead of refusing a usable machine)."""
+    import sys
+
+    sys.argv = ["bench.py"]
+    import bench
+
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(bench.Path, "glob", lambda self, pat: iter(()))      # no topology to read
+    assert bench.visible_gpu_count() is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "0,1")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0

@@ -2,9 +2,9 @@
 bit (same Philox split stream), clip -> uint16 as DataRegistration stores it (DataRegistration.py:993-995), then
 decode_one_tile (readout x predictor, low-pass, pixel decode, connected components, transcript table) - through the
 oracle and through the HIP path, compared stage by stage.  The contract is north_star's: identical transcript tables
-(integer columns and coordinates), floats within tolerance.  In the all-bits test the solver is capped at four
-iterations on both sides to keep the NumPy side to about a minute (every stage still runs at the configuration's real
-size); one bit is also run to convergence, and the decode stage is compared exactly on equal inputs."""
+(integer columns and coordinates), floats within tolerance.  Every bit runs to its own stop rule on both sides (round 4:
+the four-iteration cap of earlier rounds is gone - the sixteen NumPy deconvolutions run side by side in spawned worker
+processes on the box's host cores); the decode stage is compared exactly on equal inputs."""
 
 import warnings
 
@@ -19,7 +19,7 @@ from oracle import ccl_ref, decode_ref, rlgc_ref
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-SHAPE, N_BITS, ITERS = (16, 256, 256), 16, 4
+SHAPE, N_BITS = (16, 256, 256), 16
 
 
 def _tile(seed=0):
@@ -61,31 +61,36 @@ def test_config1_tile_oracle_and_hip_agree_from_raw_counts_to_transcripts(monkey
     cb, mat, readouts, predictors, psf = _tile()
     psf_t = torch.from_numpy(psf).to(DEV)
 
-    # ---- stage 1: deconvolution -> uint16, both paths
-    rlgc_ref.FFT_WORKERS = 16
+    # ---- stage 1: deconvolution -> uint16, both paths, every bit to its own stop
+    import multiprocessing as mp
+    import os
+    from concurrent.futures import ProcessPoolExecutor
+
+    from oracle_workers import rlgc_to_convergence
+
+    n_proc = max(1, min(8, (os.cpu_count() or 2) // 2))
+    with ProcessPoolExecutor(n_proc, mp_context=mp.get_context("spawn")) as pool:     # children never touch the GPU
+        refs = list(pool.map(rlgc_to_convergence, [(readouts[b], psf, 42, 2) for b in range(N_BITS)]))
     decon_ref, decon_hip, flips, iters = [], [], 0, []
-    try:
-        for b in range(N_BITS):
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                ref, rinfo = rlgc_ref.rlgc(readouts[b], psf, rng="philox", rng_seed=42, max_iterations=ITERS,
-                                           return_info=True)
-            out, info = rl.rlgc_device(torch.from_numpy(readouts[b]).to(DEV), psf_t, rng_seed=42, max_iterations=ITERS)
-            assert (info.iterations, info.stop_reason) == (rinfo.iterations, rinfo.stop_reason)
-            iters.append(info.iterations)
-            u_ref = np.clip(ref, 0, 65535).astype(np.uint16)
-            u_hip = kernels.clip_to_u16(out).cpu().numpy()
-            d = np.abs(u_ref.astype(np.int64) - u_hip.astype(np.int64))
-            assert d.max() <= 1, (b, int(d.max()))        # a value that sits on an integer, nothing more
-            flips += int((d > 0).sum())
-            decon_ref.append(u_ref)
-            decon_hip.append(u_hip)
-    finally:
-        rlgc_ref.FFT_WORKERS = 0
+    for b in range(N_BITS):
+        ref, r_iters, r_stop, r_kl1 = refs[b]
+        out, info = rl.rlgc_device(torch.from_numpy(readouts[b]).to(DEV), psf_t, rng_seed=42)
+        assert (info.iterations, info.stop_reason) == (r_iters, r_stop), (b, info.iterations, info.stop_reason, r_iters, r_stop)
+        np.testing.assert_allclose(info.kld_split1, r_kl1, rtol=1e-4, atol=1e-7)
+        assert float(np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()) < 1e-4
+        iters.append(info.iterations)
+        u_ref = np.clip(ref, 0, 65535).astype(np.uint16)
+        u_hip = kernels.clip_to_u16(out).cpu().numpy()
+        d = np.abs(u_ref.astype(np.int64) - u_hip.astype(np.int64))
+        assert d.max() <= 1, (b, int(d.max()))        # a value that sits on an integer, nothing more
+        flips += int((d > 0).sum())
+        decon_ref.append(u_ref)
+        decon_hip.append(u_hip)
+    assert min(iters) >= 15, iters                    # converged runs, not capped ones
     n_vox = N_BITS * int(np.prod(SHAPE))
     print(f"\\nconfig 1 end to end: {sum(iters)} RLGC iterations; uint16 voxels that differ: {flips} of {n_vox} "
           f"({flips / n_vox:.2e}), all by one count")
-    assert flips / n_vox < 2e-3
+    assert flips / n_vox < 5e-3
 
     # ---- stage 2: decode.  Same analysis parameters on both sides (from the oracle's low-passed stack)
     stack_ref = np.stack([decon_ref[b].astype(np.float32) * predictors[b] for b in range(N_BITS)])

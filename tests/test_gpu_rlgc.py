@@ -345,64 +345,6 @@ def test_chained_passes_change_nothing(monkeypatch):
     rl.clear_rlgc_caches(clear_memory_pool=True)
 
 
-@pytest.mark.parametrize("shape,padded", [((22, 70, 72), (32, 81, 81)),       # radix-9 edges, run-time geometry
-                                          ((22, 70, 120), (32, 81, 128)),     # radix-8 edges
-                                          ((22, 27, 2040), (32, 36, 2048))])  # radix-8 edges, a fifth wave
-def test_split_chain_with_run_time_geometry_changes_nothing(monkeypatch, shape, padded):
-    """The fused split stage (k_x_inverse_split_chain) has run-time geometry builds for every length the
-    register-edge X kernels take (round 3; off by default - measured no faster than the separate kernels -
-    M3D_FFT_SPLIT_CHAIN_RT=1 turns them on): M3D_RLGC_CHAIN_SPLIT=0 sends the same solve through the separate kernels
-    (plain X inverse, k_split_ratio, two X forward passes) - same iterations, same stop, KL traces and volume to the
-    float32 rounding of a transform; a saturated patch reaches the table rows of the split."""
-    monkeypatch.setenv("M3D_FFT_SPLIT_CHAIN_RT", "1")
-    rl = pkg("utils.rlgc")
-    gen = torch.Generator(device=DEV).manual_seed(5)
-    img = torch.poisson(torch.rand(shape, device=DEV, generator=gen) * 150 + 40, generator=gen).to(torch.uint16)
-    img[3, 10:20, 20:50] = 40000
-    zz, yy, xx = torch.meshgrid(*[torch.arange(n, device=DEV) - n // 2 for n in (9, 9, 9)], indexing="ij")
-    psf = torch.exp(-0.5 * ((zz / 1.5) ** 2 + (yy / 1.5) ** 2 + (xx / 1.5) ** 2)).float()
-    out = {}
-    for split in ("1", "0"):
-        monkeypatch.setenv("M3D_RLGC_CHAIN_SPLIT", split)
-        o, info = rl.rlgc_device(img, psf, max_iterations=6, rng_seed=11)
-        out[split] = (o.clone(), info)
-        of, _ = rl.rlgc_device(img.float(), psf, max_iterations=6, rng_seed=11)   # the float instantiation
-        assert torch.equal(of, o), split
-    a, b = out["1"], out["0"]
-    assert tuple(a[1].padded_shape) == padded
-    assert (a[1].iterations, a[1].stop_reason) == (b[1].iterations, b[1].stop_reason)
-    np.testing.assert_allclose(a[1].kld_split1, b[1].kld_split1, rtol=1e-5, atol=1e-8)
-    np.testing.assert_allclose(a[1].kld_image, b[1].kld_image, rtol=1e-5, atol=1e-8)
-    assert float((a[0] - b[0]).abs().max() / b[0].abs().max()) < 2e-5
-    rl.clear_rlgc_caches(clear_memory_pool=True)
-
-
-@pytest.mark.parametrize("shape,psf_shape", [((16, 256, 256), (9, 15, 15)), ((22, 70, 120), (9, 9, 9)), ((5, 30, 100), (5, 7, 13))])
-def test_graph_replayed_loop_equals_plain_launches(monkeypatch, shape, psf_shape):
-    """Launch-bound volumes replay the solver iteration from a hipGraph (one per parity of the estimate's two buffers;
-    the photon split reads its iteration number from device memory): same kernels, same arguments - the result must
-    equal the stream-launched loop to the last bit, over enough iterations for both graphs to be replayed many times,
-    for uint16 and float32 images (two kernel instantiations) and with the support pruning off (unfused kernels)."""
-    rl = pkg("utils.rlgc")
-    img, psf = _phantom(shape, psf_shape, (1.6, 1.5, 1.5), 200, seed=31)
-    img_t, psf_t = torch.from_numpy(img).to(DEV), torch.from_numpy(psf).to(DEV)
-    out = {}
-    for graph in ("0", "1"):
-        monkeypatch.setenv("M3D_RLGC_GRAPH", graph)
-        o, info = rl.rlgc_device(img_t, psf_t, rng_seed=3)
-        of, _ = rl.rlgc_device(img_t.float(), psf_t, rng_seed=3)
-        monkeypatch.setenv("M3D_FFT_PRUNE", "0")
-        ou, uinfo = rl.rlgc_device(img_t, psf_t, rng_seed=3)
-        monkeypatch.delenv("M3D_FFT_PRUNE")
-        out[graph] = (o.clone(), info, of.clone(), ou.clone(), uinfo)
-    a, b = out["1"], out["0"]
-    assert a[1].iterations == b[1].iterations >= 8 and a[1].stop_reason == b[1].stop_reason
-    assert list(a[1].kld_split1) == list(b[1].kld_split1) and list(a[1].updated_fraction) == list(b[1].updated_fraction)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
-    assert a[4].iterations == b[4].iterations and torch.equal(a[3], b[3])
-    rl.clear_rlgc_caches(clear_memory_pool=True)
-
-
 def test_static_geometry_kernels_equal_the_generic_ones(monkeypatch):
     """Lateral size 2187 runs kernels compiled for that geometry (register-resident twiddles, unrolled middle stages,
     static Y stages, chained tails); M3D_FFT_XSTATIC=0 / M3D_FFT_YSTATIC=0 send the same solve through the run-time

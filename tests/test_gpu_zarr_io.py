@@ -203,3 +203,62 @@ def test_decode_worker_reopens_the_datastore_by_path(tmp_path):
         table = fresh.load_local_decoded_spots(tile=t)
         assert table is not None and len(table) >= 8 and set(table["gene_id"]) <= {"g0", "g1", "Blank-0"}
         assert (table["tile_idx"] == t).all()
+
+
+def test_write_behind_leaves_the_same_bytes_on_disk_and_keeps_the_tile_in_hbm(tmp_path):
+    """``write_behind=True``: saves return at once and run on a background thread with its own stream; what lands on
+    disk is byte-identical to the synchronous store's files, a load of a volume whose write is still queued comes from
+    HBM, ``evict_tile`` + ``flush`` leave only the disk copy, and ``prefetch_tile_inputs`` reads the preprocess's
+    inputs ahead in the order the operators ask for them."""
+    ds = pkg("datastore")
+    from helpers import codebook_frame
+
+    rng = np.random.default_rng(21)
+    cb = codebook_frame(np.ones((3, 3), dtype=np.int64))
+    kw = dict(device=DEV, num_threads=2, num_tiles=2, num_rounds=2, num_bits=3, codebook=cb)
+    lazy = ds.ZarrImageDataStore(tmp_path / "lazy", write_behind=True, prefetch_threads=2, write_threads=3,
+                                 max_pending_writes=2, **kw)
+    eager = ds.ZarrImageDataStore(tmp_path / "eager", **kw)
+    vols = {}
+    for t in range(2):
+        for r in range(2):
+            v = torch.from_numpy(rng.integers(80, 9000, size=(18, 130, 520)).astype(np.uint16)).to(DEV)
+            vols[(t, "round", r)] = v
+            for s in (lazy, eager):
+                s.set_corrected_image(v, tile=t, round=r)
+        for b in range(3):
+            v = torch.from_numpy(rng.integers(80, 9000, size=(18, 130, 520)).astype(np.uint16)).to(DEV)
+            p = torch.from_numpy(rng.uniform(size=(18, 130, 520)).astype(np.float32)).to(DEV)
+            vols[(t, "bit", b)] = (v, p)
+            for s in (lazy, eager):
+                s.set_corrected_image(v, tile=t, bit=b)
+                s.save_local_feature_predictor_image(p, tile=t, bit=b)
+    assert len(lazy._pending_writes) <= 2                           # back-pressure held the queue at its bound
+    got = lazy.load_local_corrected_image(1, bit=2, return_future=False)
+    assert got.data_ptr() == vols[(1, "bit", 2)][0].data_ptr()      # still resident: no I/O
+    lazy.flush()
+    assert not lazy._pending_writes
+    for path in sorted((tmp_path / "eager").rglob("*")):
+        if path.is_file():
+            twin = tmp_path / "lazy" / path.relative_to(tmp_path / "eager")
+            assert twin.exists() and twin.read_bytes() == path.read_bytes(), path
+    assert lazy.evict_tile(1) == 2 + 3 + 3 and lazy.evict_tile(0) == 8 and not lazy._resident
+    # read-ahead of a tile's preprocess inputs: fiducials of both rounds, then readout + predictor per bit
+    assert lazy.prefetch_tile_inputs(1) == 2 + 6
+    busy = torch.ones((1024, 1024), device=DEV)
+    for _ in range(10):
+        busy = busy @ busy * 1e-3
+    for r in range(2):
+        assert torch.equal(lazy.load_local_corrected_image(1, round=r, return_future=False), vols[(1, "round", r)])
+    for b in range(3):
+        assert torch.equal(lazy.load_local_corrected_image(1, bit=b, return_future=False), vols[(1, "bit", b)][0])
+        assert torch.equal(lazy.load_local_feature_predictor_image(1, bit=b, return_future=False), vols[(1, "bit", b)][1])
+    assert not lazy._prefetched
+    # a deconvolved volume saved behind the compute shadows the corrected one at once and survives eviction on disk
+    half = (vols[(0, "bit", 1)][0].to(torch.int32) // 2).to(torch.uint16)
+    lazy.save_local_deconvolved_readout_image(half, tile=0, bit=1)
+    assert lazy.load_local_readout_image(0, bit=1, return_future=False).data_ptr() == half.data_ptr()
+    assert lazy._image_shape(0, bit=1, kind="decon_data") == (18, 130, 520)
+    lazy.evict_tile(0)
+    assert torch.equal(lazy.load_local_readout_image(0, bit=1, return_future=False), half)   # waits for the write
+    torch.cuda.synchronize()
