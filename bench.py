@@ -611,7 +611,10 @@ def main() -> int:
             progress(f"bit {b + 1}/{n_bits}: {info.iterations} RLGC iterations ({info.stop_reason})")
 
     def decode(slot: int = 0) -> None:
+        t0 = time.perf_counter()
         decoder.decode_one_tile(tile_idx=slot, gpu_id=gpu_index, normalization_method="global")
+        torch.cuda.current_stream(device).synchronize()
+        stats["phase_s"]["decode_one_tile"] = stats["phase_s"].get("decode_one_tile", 0.0) + time.perf_counter() - t0
         stats["transcripts"] = len(decoder.decoded_barcodes)
         stats["table"] = decoder.decoded_barcodes[["tile_z", "tile_y", "tile_x", "barcode_id"]]
         stats["truth"] = slot_truth[slot]["truth"] if disk else current["truth"]

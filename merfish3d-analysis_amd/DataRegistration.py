@@ -387,6 +387,9 @@ class DataRegistration:
         self._feature_predictor = feature_predictor
         self._tile_id = None
         self._tile_parallel = False
+        # rounds whose registration stands apart from their tile's other rounds (see _audit_round_transforms)
+        self.suspect_registrations: dict = {}
+        self.suspect_registrations_all_ranks: int | None = None
 
     # ----------------------------------------------------------------- properties (:1237-1344)
     @property
@@ -521,13 +524,25 @@ class DataRegistration:
             for tile_id in mine:
                 self.tile_id = tile_id
                 self._generate_registrations()
+                self._audit_round_transforms()
                 self._apply_registration_to_bits()
         finally:
             tile_parallel, self._tile_parallel = self._tile_parallel, False
+        count = sum(len(v) for v in self.suspect_registrations.values())
         if tile_parallel:
+            import torch
             import torch.distributed as dist
 
+            total = torch.tensor([count], dtype=torch.int64,
+                                 device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)      # 8 bytes over RCCL / xGMI: every rank knows the job's count
+            count = int(total.item())
             dist.barrier()
+        self.suspect_registrations_all_ranks = count
+        if count:
+            print(time_stamp(), f"WARNING: {count} round registration(s) stand apart from their tile's other rounds by more "
+                                "than a quarter of the image (see DataRegistration.suspect_registrations): the phase-correlation "
+                                "disambiguation can pick a wrapped twin of the true shift.", flush=True)
         if self._global_registration:
             self.global_register()
 
@@ -668,6 +683,42 @@ class DataRegistration:
                            f"elapsed_s={timeit.default_timer() - start_time:.2f}",
                            enabled=self._registration_diagnostics)
         gc.collect()
+
+    def _audit_round_transforms(self) -> list:
+        """Make mis-registrations visible (parity behaviour unchanged: nothing is corrected).
+
+        ``phase_cross_correlation(disambiguate=True)`` - scikit-image's rule, restated here as the reference calls it
+        (multiview_registration.py:265-301) - chooses between a shift and its wrapped twins by correlating the
+        overlap tiles and accepts tiles of three samples; on the 2-D projection stage a shift of about (+-3, +-1) px
+        gives such a corner tile, which wins about one time in seven and registers the round an image width off
+        (on the F1 fixture of tests/golden/f1_reference_run.json it happens to round 6).  A
+        wrapped twin differs from the truth by about the image extent, real round-to-round drifts are a few pixels:
+        a round whose translation is further than a QUARTER of the image extent (any axis) from the median over the
+        tile's rounds is recorded in ``self.suspect_registrations[tile_id]`` as ``(round_id, shift_px, median_px)``.
+        ``register_all_tiles`` sums the count over all ranks and prints one warning."""
+        ds = self._datastore
+        spacing = np.asarray(ds.voxel_size_zyx_um, dtype=np.float64)
+        shifts, rounds = [], []
+        for round_id in self._round_ids:
+            T = ds.load_local_round_transform_zyx_um(tile=self._tile_id, round=round_id)
+            if T is None:
+                continue
+            shifts.append(np.asarray(T, dtype=np.float64)[:3, 3] / spacing)
+            rounds.append(round_id)
+        suspects = []
+        if len(shifts) >= 3:
+            shape = self._shape_of(self._tile_id, "corrected_data", round_id=self._round_ids[0])
+            if shape is not None:
+                extent = np.asarray(tuple(shape)[-3:], dtype=np.float64)
+                shifts = np.asarray(shifts)
+                median = np.median(shifts, axis=0)
+                far = np.any(np.abs(shifts - median) > 0.25 * extent, axis=1)
+                suspects = [(rounds[i], shifts[i].round(2).tolist(), median.round(2).tolist()) for i in np.nonzero(far)[0]]
+        if suspects:
+            self.suspect_registrations[self._tile_id] = suspects
+        else:
+            self.suspect_registrations.pop(self._tile_id, None)
+        return suspects
 
     def _apply_registration_to_bits(self) -> None:
         """Deconvolve readout bits, run the feature predictor, save unwarped outputs (:2272-2315)."""

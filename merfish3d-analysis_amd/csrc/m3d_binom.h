@@ -20,7 +20,7 @@
 // The search for D starts from an arithmetic guess - the normal quantile of the tail mass with the binomial's
 // kurtosis and lattice corrections, off by one threshold about once in 10^4 draws - and is then decided by the
 // exact integers alone: one 16-byte load of the two thresholds around the guess settles almost every draw, a wrong
-// guess moves on (at most four probes, then bisection), so the float arithmetic of the guess, which differs between
+// guess falls back to a bisection over the whole row, so the float arithmetic of the guess, which differs between
 // host and device, cannot change a result.  A per-lane gather costs the L1 one tag look-up per distinct line and,
 // when the rows in use exceed its 32 KB, a line from L2: six of them per draw (a guide table + bisection, the first
 // version) made the kernel 3.9 x slower on a saturated image than on a dim one, the single one 2 x

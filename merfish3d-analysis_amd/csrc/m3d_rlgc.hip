@@ -574,14 +574,24 @@ __global__ void k_clip_u16(const float *__restrict__ in, uint16_t *__restrict__ 
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
-// The split sampler's threshold / guide tables (m3d_binom.h): built once per process, one copy per device.
-int device_binom_tables(BinomTables *out)
+// The split sampler's threshold tables (m3d_binom.h: 1024 rows of exact integer thresholds, 9.6 MB): built once per
+// process on the host, one copy per device, kept for the life of the process.  `on` (optional): a device pointer of the
+// caller (the image): the tables are taken for the device that owns it, which must be the current one - a kernel
+// launched on this device's stream with another device's table pointer would fault.
+int device_binom_tables(BinomTables *out, const void *on = nullptr)
 {
     static std::mutex mu;
     static BinomTables per_device[64] = {};
     int dev = 0;
     M3D_HIP_CHECK(hipGetDevice(&dev));
     M3D_REQUIRE(dev >= 0 && dev < 64, "device index");
+    if (on) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, on) == hipSuccess && attr.type == hipMemoryTypeDevice)
+            M3D_REQUIRE(attr.device == dev, "the image lives on another device than the current one");
+        else
+            (void)hipGetLastError();  // (host / unregistered pointers: nothing to check)
+    }
     std::lock_guard<std::mutex> lock(mu);
     if (!per_device[dev].thr) {
         const BinomTablesHost &h = binom_tables_host();
@@ -591,10 +601,16 @@ int device_binom_tables(BinomTables *out)
         }
         uint64_t *thr = nullptr;
         BinomRow *rows = nullptr;
-        M3D_HIP_CHECK(hipMalloc(&thr, h.thr.size() * sizeof(uint64_t)));
-        M3D_HIP_CHECK(hipMalloc(&rows, h.rows.size() * sizeof(BinomRow)));
-        M3D_HIP_CHECK(hipMemcpy(thr, h.thr.data(), h.thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        M3D_HIP_CHECK(hipMemcpy(rows, h.rows.data(), h.rows.size() * sizeof(BinomRow), hipMemcpyHostToDevice));
+        hipError_t e = hipMalloc(&thr, h.thr.size() * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc(&rows, h.rows.size() * sizeof(BinomRow));
+        if (e == hipSuccess) e = hipMemcpy(thr, h.thr.data(), h.thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(rows, h.rows.data(), h.rows.size() * sizeof(BinomRow), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {  // nothing half-made stays behind
+            if (thr) (void)hipFree(thr);
+            if (rows) (void)hipFree(rows);
+            set_err("binomial split tables", hipGetErrorString(e));
+            return e == hipErrorOutOfMemory ? M3D_ERR_OUT_OF_MEMORY : M3D_ERR_HIP;
+        }
         per_device[dev] = BinomTables{thr, rows};
     }
     *out = per_device[dev];
@@ -840,7 +856,7 @@ int m3d_rlgc_run(m3d_rlgc_plan *p, const void *image, int image_dtype, const flo
     }
     hipStream_t st = (hipStream_t)stream_v;
     BinomTables binom;
-    if (int rc_tables = device_binom_tables(&binom)) return rc_tables;
+    if (int rc_tables = device_binom_tables(&binom, image)) return rc_tables;
     // (Round 3 could replay the loop body from hipGraphs - bit-equal and measured no faster at any size on MI355X / ROCm 7.2,
     // profiles/r03_graph_replay.txt: a launch-bound iteration waits for the dispatch latency between dependent kernels and
     // the stop test's read-back, neither of which a graph removes.  The path was taken out in round 4.)

@@ -284,9 +284,15 @@ def convert_data(root_path, datastore_factory: Callable | None = None, *, codebo
                  channel_names: Sequence[str] | None = None, default_tile_overlap: float = 0.2):
     """Acquisition folder -> datastore (convert_to_datastore.py:185-573) and return the datastore.
 
-    ``datastore_factory(num_tiles=, num_rounds=, num_bits=, codebook=, voxel_size_zyx_um=, microscope_type=)`` builds
-    the store (default: ``datastore.InMemoryDataStore``; ``ZarrImageDataStore`` / ``Qi2labDiskStore`` take the same
-    keywords after their path).  Per round: channel 0 is the fiducial image (PSF 0), channels 1 and 2 the readouts of
+    ``datastore_factory`` builds the store (default: ``datastore.InMemoryDataStore``; ``ZarrImageDataStore`` /
+    ``Qi2labDiskStore`` take the same keywords after their path).  It is called with the keywords
+    ``num_tiles, num_rounds, num_bits, codebook, voxel_size_zyx_um, microscope_type`` and - the experiment constants the
+    reference writes at creation (convert_to_datastore.py:271-330) - ``experiment_order, channels_in_data,
+    camera_model, tile_overlap, binning, na, ri, e_per_ADU``; the store it returns must answer
+    ``save_local_corrected_image``, ``save_local_wavelengths_um``, ``save_local_stage_position_zyx_um`` and derive every
+    bit's round link from ``experiment_order`` (``initialize_tile`` in the reference).  A store that exposes
+    ``set_round_linker`` but has no link for a bit after creation gets it set here; a bit without a link afterwards is an
+    error, not a silent default.  Per round: channel 0 is the fiducial image (PSF 0), channels 1 and 2 the readouts of
     the bits ``bit_order[round, 1:3]`` (1-based)."""
     if z_step <= 0:
         raise ValueError("z_step must be greater than 0.")
@@ -380,12 +386,35 @@ def convert_data(root_path, datastore_factory: Callable | None = None, *, codebo
                 bit_id = store.bit_ids[bit]
                 store.save_local_corrected_image(image, tile=tile_id, psf_idx=ch, gain_correction=True,
                                                  hotpixel_correction=False, shading_correction=False, bit=bit_id)
-                store.save_local_wavelengths_um((ex[ch], em[ch]), tile=tile_id, bit=bit_id)   # the bit's round link
-                # comes from the experiment order the store was created with (initialize_tile in the reference)
+                store.save_local_wavelengths_um((ex[ch], em[ch]), tile=tile_id, bit=bit_id)
+                # the bit's round link comes from the experiment order the store was created with (initialize_tile in the
+                # reference); a factory written to the older six-keyword contract may not have derived it
+                want_round = int(experiment_order[r, 0])
+                linked = _stored_round_link(store, tile_id, bit_id)
+                if linked != want_round and callable(getattr(store, "set_round_linker", None)):
+                    store.set_round_linker(tile_id, bit_id, want_round)
+                    linked = _stored_round_link(store, tile_id, bit_id)
+                if linked != want_round:
+                    raise RuntimeError(f"datastore holds round link {linked!r} for {tile_id}/{bit_id}, the bit order says "
+                                       f"{want_round}: the factory must take experiment_order or expose set_round_linker")
     state = dict(store.datastore_state or {})
     state.update({"Corrected": True})
     store.datastore_state = state
     return store
+
+
+def _stored_round_link(store, tile_id, bit_id):
+    """The 1-based round a bit is linked to as the store itself holds it (None: no link), without the in-memory
+    store's default of 1 for unknown bits."""
+    from .datastore import InMemoryDataStore
+
+    if getattr(type(store), "load_local_round_linker", None) is InMemoryDataStore.load_local_round_linker:
+        return store._round_linker.get((tile_id, bit_id))
+    try:
+        value = store.load_local_round_linker(tile_id, bit_id)
+    except (KeyError, FileNotFoundError, AttributeError):
+        return None
+    return None if value is None else int(value)
 
 
 def _apply_synthetic_chromatic_aberration(image_zyx, emission_wavelength_um, voxel, emission_wavelengths_um, shift_scale,

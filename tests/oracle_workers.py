@@ -7,7 +7,8 @@ import warnings
 
 
 def rlgc_to_convergence(job):
-    """(image uint16, psf, seed, fft_workers) -> (float32 volume, iterations, stop reason, KL trace of split 1)."""
+    """(image uint16, psf, seed, fft_workers[, max_iterations]) -> (float32 volume, iterations, stop reason, KL traces
+    of split 1 and split 2)."""
     import sys
     from pathlib import Path
 
@@ -16,12 +17,13 @@ def rlgc_to_convergence(job):
         sys.path.insert(0, root)
     from oracle import rlgc_ref
 
-    image, psf, seed, workers = job
+    image, psf, seed, workers = job[:4]
+    cap = job[4] if len(job) > 4 else None
     rlgc_ref.FFT_WORKERS = int(workers)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        out, info = rlgc_ref.rlgc(image, psf, rng="philox", rng_seed=seed, return_info=True)
-    return out, info.iterations, info.stop_reason, list(info.kld_split1)
+        out, info = rlgc_ref.rlgc(image, psf, rng="philox", rng_seed=seed, return_info=True, max_iterations=cap)
+    return out, info.iterations, info.stop_reason, list(info.kld_split1), list(info.kld_split2)
 
 
 def rlgc_reference_stream(job):

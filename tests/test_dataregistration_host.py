@@ -120,3 +120,29 @@ def test_no_gpus_is_an_error():
     reg.tile_id = 0
     with pytest.raises(RuntimeError):
         reg._apply_registration_to_bits()
+
+
+def test_audit_flags_the_round_that_sits_an_image_width_off():
+    """Round 4: a wrapped twin of the true shift (phase_cross_correlation's three-sample corner tile) is made visible -
+    the shifts of the F1 fixture's mis-registered dataset: seven rounds within a few pixels, one 254 px away."""
+    dr = pkg("DataRegistration")
+    ds = _store(num_tiles=1, num_rounds=8, shape=(16, 256, 256))
+    spacing = np.asarray(ds.voxel_size_zyx_um, dtype=np.float64)
+    found = [[0.0, 0.0, 0.0], [0.3, 2.4, -2.5], [-0.2, -1.1, 3.8], [0.1, 3.9, 1.3], [-0.0, -2.7, -4.1],
+             [5.9, -254.2, 125.6], [-0.3, -3.5, -1.5], [0.1, 2.5, -2.3]]
+    t = ds.tile_ids[0]
+    for rid, shift in zip(ds.round_ids, found):
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = np.asarray(shift) * spacing
+        ds.save_local_round_transform_zyx_um(T, tile=t, round=rid)
+    reg = dr.DataRegistration(ds, verbose=0)
+    reg.tile_id = t
+    suspects = reg._audit_round_transforms()
+    assert [s[0] for s in suspects] == [ds.round_ids[5]]
+    np.testing.assert_allclose(suspects[0][1], found[5], atol=0.02)      # shifts are held as float32 microns
+    assert reg.suspect_registrations == {t: suspects}
+    # the same tile with that round repaired: nothing to report, and the record is cleared
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = np.asarray([0.5, 1.2, 3.9]) * spacing
+    ds.save_local_round_transform_zyx_um(T, tile=t, round=ds.round_ids[5])
+    assert reg._audit_round_transforms() == [] and reg.suspect_registrations == {}

@@ -71,13 +71,32 @@ def test_config1_tile_oracle_and_hip_agree_from_raw_counts_to_transcripts(monkey
     n_proc = max(1, min(8, (os.cpu_count() or 2) // 2))
     with ProcessPoolExecutor(n_proc, mp_context=mp.get_context("spawn")) as pool:     # children never touch the GPU
         refs = list(pool.map(rlgc_to_convergence, [(readouts[b], psf, 42, 2) for b in range(N_BITS)]))
-    decon_ref, decon_hip, flips, iters = [], [], 0, []
+    decon_ref, decon_hip, flips, iters, plateau = [], [], 0, [], []
     for b in range(N_BITS):
-        ref, r_iters, r_stop, r_kl1 = refs[b]
-        out, info = rl.rlgc_device(torch.from_numpy(readouts[b]).to(DEV), psf_t, rng_seed=42)
-        assert (info.iterations, info.stop_reason) == (r_iters, r_stop), (b, info.iterations, info.stop_reason, r_iters, r_stop)
-        np.testing.assert_allclose(info.kld_split1, r_kl1, rtol=1e-4, atol=1e-7)
-        assert float(np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()) < 1e-4
+        ref, r_iters, r_stop, r_kl1, r_kl2 = refs[b]
+        img_t = torch.from_numpy(readouts[b]).to(DEV)
+        out, info = rl.rlgc_device(img_t, psf_t, rng_seed=42)
+        n = min(len(info.kld_split1), len(r_kl1))
+        np.testing.assert_allclose(info.kld_split1[:n], r_kl1[:n], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(info.kld_split2[:n], r_kl2[:n], rtol=1e-4, atol=1e-7)
+        if (info.iterations, info.stop_reason) != (r_iters, r_stop):
+            # The stop rule compares successive KL values (rlgc.py:630-649); on the plateau they differ by less than the
+            # 1e-4 to which two float32 implementations of the sums agree, and the side whose rounding tips the test
+            # first stops a few (almost idle) iterations earlier.  Legitimate only if the decision WAS that close: the
+            # side that went on saw its tripping KL move by less than 2e-4 (relative) at that iteration.  Both sides are
+            # then compared at the earlier stop: the later one is re-run with the iteration cap that returns the same
+            # estimate (a restore at count k hands back the estimate of k - 1 updates).
+            k = min(info.iterations, r_iters)
+            late = (info.kld_split1, info.kld_split2) if info.iterations > r_iters else (r_kl1, r_kl2)
+            margin = min(abs(tr[k] - tr[k - 1]) / tr[k] for tr in late)
+            assert margin < 2e-4, (b, info.iterations, r_iters, margin)
+            assert info.stop_reason == r_stop == "restore_previous_recon", (b, info.stop_reason, r_stop)
+            plateau.append((b, info.iterations, r_iters, float(margin)))
+            if info.iterations > r_iters:
+                out, info = rl.rlgc_device(img_t, psf_t, rng_seed=42, max_iterations=k - 1)
+            else:
+                ref = rlgc_to_convergence((readouts[b], psf, 42, 16, k - 1))[0]
+        assert float(np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()) < 1e-4, b
         iters.append(info.iterations)
         u_ref = np.clip(ref, 0, 65535).astype(np.uint16)
         u_hip = kernels.clip_to_u16(out).cpu().numpy()
@@ -86,6 +105,8 @@ def test_config1_tile_oracle_and_hip_agree_from_raw_counts_to_transcripts(monkey
         flips += int((d > 0).sum())
         decon_ref.append(u_ref)
         decon_hip.append(u_hip)
+    print(f"\nbits whose stop fell on the KL plateau (bit, HIP iterations, oracle iterations, margin): {plateau}")
+    assert len(plateau) <= 3, plateau
     assert min(iters) >= 15, iters                    # converged runs, not capped ones
     n_vox = N_BITS * int(np.prod(SHAPE))
     print(f"\\nconfig 1 end to end: {sum(iters)} RLGC iterations; uint16 voxels that differ: {flips} of {n_vox} "

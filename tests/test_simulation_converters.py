@@ -108,6 +108,39 @@ def test_convert_data_applies_gain_offset_channel_order_and_links(sim, tmp_path)
         sim.convert_data(acq, z_step=0)
 
 
+def test_convert_data_sets_or_demands_the_round_links_of_a_factory_that_ignores_the_bit_order(sim, tmp_path):
+    """a factory written to the older six-keyword contract drops ``experiment_order``; the converter
+    then sets every bit's round link itself through ``set_round_linker`` - and refuses a store that offers no way to
+    hold one instead of leaving every bit on round 1."""
+    from conftest import pkg
+
+    ds = pkg("datastore")
+    acq = sim.convert_simulation(_dataset(sim, tmp_path))
+    order = pd.read_csv(acq / "bit_order.csv").values
+
+    def six_keyword_factory(**kw):
+        keep = ("num_tiles", "num_rounds", "num_bits", "codebook", "voxel_size_zyx_um", "microscope_type")
+        return ds.InMemoryDataStore(**{k: kw[k] for k in keep})
+
+    store = sim.convert_data(acq, datastore_factory=six_keyword_factory)
+    for r in range(order.shape[0]):
+        for ch in (1, 2):
+            assert store.load_local_round_linker(store.tile_ids[0], store.bit_ids[int(order[r, ch]) - 1]) == int(order[r, 0])
+
+    class NoLinks(ds.InMemoryDataStore):
+        set_round_linker = None
+
+        def load_local_round_linker(self, tile, bit):
+            return None
+
+    def linkless_factory(**kw):
+        keep = ("num_tiles", "num_rounds", "num_bits", "codebook", "voxel_size_zyx_um", "microscope_type")
+        return NoLinks(**{k: kw[k] for k in keep})
+
+    with pytest.raises(RuntimeError, match="round link"):
+        sim.convert_data(acq, datastore_factory=linkless_factory)
+
+
 def test_calculate_f1_conventions(sim, tmp_path):
     """A decoded table placed exactly on the ground truth scores 1; without the z-centre shift or with X and Y read
     the plain way it would not."""
