@@ -526,6 +526,15 @@ class DataRegistration:
                 self._generate_registrations()
                 self._audit_round_transforms()
                 self._apply_registration_to_bits()
+                # a write-behind store (datastore.ZarrImageDataStore(write_behind=True)) keeps what it was handed
+                # readable from HBM while its writer thread works: a finished tile's copies are dropped here - the
+                # queued writes hold their own references - or the volumes of a whole dataset would pile up
+                evict = getattr(self._datastore, "evict_tile", None)
+                if callable(evict):
+                    evict(tile_id)
+            flush = getattr(self._datastore, "flush", None)
+            if callable(flush):
+                flush()                       # everything this call produced is on disk when it returns
         finally:
             tile_parallel, self._tile_parallel = self._tile_parallel, False
         count = sum(len(v) for v in self.suspect_registrations.values())

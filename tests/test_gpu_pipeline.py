@@ -49,9 +49,10 @@ def _render(points, amps, sigma):
     return gaussian_filter(vol, sigma)
 
 
-def _experiment(seed=0, zarr_root=None):
+def _experiment(seed=0, zarr_root=None, write_behind=False):
     """(store, truth table, per-round shifts): 2 tiles side by side in y with a 28-px overlap.
-    ``zarr_root``: keep every image on disk as OME-Zarr and load it straight into HBM (I/O fast path)."""
+    ``zarr_root``: keep every image on disk as OME-Zarr and load it straight into HBM (I/O fast path);
+    ``write_behind``: image saves queued to the store's background writer (round 4)."""
     ds_mod = pkg("datastore")
     rng = np.random.default_rng(seed)
     bits, genes = _codebook()
@@ -60,7 +61,8 @@ def _experiment(seed=0, zarr_root=None):
     if zarr_root is None:
         store = ds_mod.InMemoryDataStore(**kwargs)
     else:   # images as OME-Zarr, metadata as the reference's JSON sidecars / parquet tables
-        store = pkg("qi2lab_store").Qi2labDiskStore(zarr_root, device="cuda:0", num_threads=4, **kwargs)
+        store = pkg("qi2lab_store").Qi2labDiskStore(zarr_root, device="cuda:0", num_threads=4,
+                                                    write_behind=write_behind, write_threads=4, **kwargs)
     store.channel_psfs = [_psf((0.9, 1.2, 1.2)), _psf((0.9, 1.3, 1.3)), _psf((0.9, 1.4, 1.4))]
     shifts = {r: (0.0, 0.0, 0.0) if r == 0 else tuple(np.round(rng.uniform((-1, -4, -4), (1, 4, 4)), 0))
               for r in range(N_ROUNDS)}
@@ -96,10 +98,11 @@ def _experiment(seed=0, zarr_root=None):
     return store, truth, shifts, predictors
 
 
-@pytest.mark.parametrize("deformable,on_disk", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("deformable,on_disk", [(False, False), (True, False), (True, True), (False, "write_behind")])
 def test_preprocess_then_decode_recovers_the_planted_transcripts(deformable, on_disk, tmp_path):
     DR, PD, sc = pkg("DataRegistration"), pkg("PixelDecoder"), pkg("scoring")
-    store, truth, shifts, predictors = _experiment(zarr_root=tmp_path / "qi2lab" if on_disk else None)
+    store, truth, shifts, predictors = _experiment(zarr_root=tmp_path / "qi2lab" if on_disk else None,
+                                                   write_behind=on_disk == "write_behind")
     state = {}
 
     def predictor(image):
@@ -122,6 +125,8 @@ def test_preprocess_then_decode_recovers_the_planted_transcripts(deformable, on_
                               perform_deformable_registration=deformable, verbose=0, feature_predictor=predictor)
     reg.register_all_tiles()
     store.load_local_corrected_image = load
+    if on_disk == "write_behind":   # register_all_tiles evicted its tiles and flushed the queue before returning
+        assert not store._resident and not store._pending_writes
     for tile in store.tile_ids:
         for r, rid in enumerate(store.round_ids):
             T = store.load_local_round_transform_zyx_um(tile, rid)
