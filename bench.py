@@ -478,7 +478,7 @@ def main() -> int:
         QS = importlib.import_module("merfish3d-analysis_amd.qi2lab_store")
         base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
         io_root = Path(tempfile.mkdtemp(prefix=f"m3d_bench_store_r{rank}_", dir=base))
-        n_slots = len(contiguous_share(args.tiles, world, rank)) if strong else 1
+        n_slots = len(contiguous_share(args.tiles, world, rank)) if strong else 2   # weak: the rank's tile twice, see slot_of
         store = QS.Qi2labDiskStore(io_root, device=device, num_threads=4, write_behind=True,
                                    prefetch_threads=args.io_read_threads, write_threads=args.io_write_threads,
                                    max_pending_writes=args.io_queue,
@@ -835,6 +835,8 @@ def main() -> int:
     if strong and args.tiles < world:
         raise SystemExit(f"config3 deals whole tiles: --tiles {args.tiles} < {world} ranks")
     load_tile((100 + my_tiles[0]) if strong else (1 + rank), 0)
+    if disk and not strong:
+        load_tile(1 + rank, 1)
     progress("synthetic tile ready" + (f" and written to {io_root}" if disk else ""))
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -897,7 +899,12 @@ def main() -> int:
         store.io_counts.clear()
 
     def slot_of(i: int) -> int:
-        return i if (strong and disk) else 0   # the in-memory store holds one tile; the disk store the rank's share
+        # the in-memory store holds one tile; the disk store holds the rank's share (strong scaling) or - weak scaling,
+        # where every step re-runs the rank's one tile - two copies of it, so that step i + 1's read-ahead has its own
+        # images to load while step i consumes its own
+        if not disk:
+            return 0
+        return i if strong else i % 2
 
     def prepare_slot(i: int) -> None:
         """--store disk, untimed: the input images of timed step i on disk before any step needs them."""
