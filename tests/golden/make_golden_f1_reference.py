@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One cell of the simulation F1 matrix run through the REFERENCE's own code (authoring container only):
 
-    python tests/golden/make_golden_f1_reference.py          # ~20 min on 8 cores
+    python tests/golden/make_golden_f1_reference.py [cell ...]     # ~15 min per cell on 8 cores; default: dz0.315
 
-Dataset: the dz = 0.315 um cell of tests/oracle_pipeline.py (16 x 256 x 256, 8 rounds x (fiducial + 2 bits), seeds
-fixed).  With the stand-ins of make_golden.py (cupy -> NumPy, cupyx.scipy.ndimage -> SciPy, cuVS distance -> expanded
+Dataset: a cell of the simulation matrix of tests/oracle_pipeline.py (dz0.315 / dz1.0 / dz1.5: 16 x 256 x 256, 8 rounds x
+(fiducial + 2 bits), seeds fixed; the two coarser spacings decode per plane, PixelDecoder's 2-D mode).  With the stand-ins of make_golden.py (cupy -> NumPy, cupyx.scipy.ndimage -> SciPy, cuVS distance -> expanded
 float32 form, scikit-image / cuCIM label + regionprops -> oracle.ccl_ref, itself pinned to scikit-image 0.18.3) the
 reference executes, chained on ONE dataset for the first time:
 
@@ -21,9 +21,10 @@ column downstream of registration; what the oracle's restatement finds is record
 the shared difference-of-Gaussians stand-in of tests/oracle_pipeline.py) and the transforms' FFT backend (scipy.fft
 with worker threads stands in for cuFFT where make_golden.py uses numpy.fft; same mathematics, last-bit differences).
 
-Output: tests/golden/f1_reference_run.json - the scorer's dictionary, the round transforms, per-volume RLGC iteration
-counts (from the reference's own log lines), transcript counts before / after the filter, the iterative normalisation
-vectors.  tests/test_gpu_f1_reference_run.py runs the HIP pipeline from the same transforms and asserts
+Output: tests/golden/f1_reference_run.json, one entry per cell - the scorer's dictionary, the round transforms,
+per-volume RLGC iteration counts (from the reference's own log lines), transcript counts before / after the filter, the
+iterative normalisation vectors, and ``oracle_pipeline_same_transforms``: the ORACLE pipeline (Philox split stream) run
+from the same transforms, the twin the HIP pipeline's own stream is held to.  tests/test_gpu_f1_reference_run.py runs the HIP pipeline from the same transforms and asserts
 |F1_hip - F1_reference| <= 0.005 (BASELINE.json north_star); tests/test_oracle_golden.py holds the oracle pipeline's
 affine cell (f1_matrix.json) to the same bound.
 """
@@ -49,10 +50,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import make_golden as mg  # noqa: E402  (stand-ins + import of the reference)
 
-CELL = "dz0.315"
-
-
-def main() -> None:
+def run_cell(CELL: str) -> dict:
     t_start = time.time()
 
     def progress(msg):
@@ -176,8 +174,26 @@ def main() -> None:
             "background": np.round(np.asarray(bkd, dtype=float), 1).tolist(),
             "seconds": round(time.time() - t_start, 1),
         }
-    (HERE / "f1_reference_run.json").write_text(json.dumps(out, indent=1, sort_keys=True))
-    print("wrote", HERE / "f1_reference_run.json", out["f1"])
+        # ---- the oracle pipeline (the build's Philox stream) from the same transforms, on a fresh copy of the dataset
+        t1 = time.time()
+        store2, gt2 = op.make_cell(work / "oracle", CELL)
+        res = op.oracle_readouts_then_score(store2, gt2, transforms, float(cell["radius"]), dict(cell["decode"]))
+        out["oracle_pipeline_same_transforms"] = {
+            k: (float(v) if isinstance(v, (float, np.floating)) else (int(v) if isinstance(v, (int, np.integer)) else v))
+            for k, v in res.items()}
+        out["oracle_pipeline_seconds"] = round(time.time() - t1, 1)
+        progress(f"oracle pipeline, same transforms: {out['oracle_pipeline_same_transforms']['F1 Score']:.4f}")
+    return out
+
+
+def main() -> None:
+    cells = sys.argv[1:] or ["dz0.315"]
+    path = HERE / "f1_reference_run.json"
+    results = json.loads(path.read_text()) if path.exists() else {}
+    for name in cells:
+        results[name] = run_cell(name)
+        path.write_text(json.dumps(results, indent=1, sort_keys=True))
+        print("wrote", path, name, results[name]["f1"])
 
 
 if __name__ == "__main__":

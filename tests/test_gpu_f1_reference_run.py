@@ -26,8 +26,14 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_hip_pipeline_f1_stands_with_the_reference_run(tmp_path):
-    fx = json.loads((GOLDEN / "f1_reference_run.json").read_text())
+def _cells():
+    return sorted(json.loads((GOLDEN / "f1_reference_run.json").read_text()))
+
+
+@pytest.mark.parametrize("name", _cells())
+def test_hip_pipeline_f1_stands_with_the_reference_run(name, tmp_path):
+    fx = json.loads((GOLDEN / "f1_reference_run.json").read_text())[name]
+    assert fx["cell"] == name
     cell = op.CELLS[fx["cell"]]
     assert fx["seed"] == cell["seed"] and fx["shifts"] == [list(s) for s in cell["shifts"]]
     transforms = [np.asarray(T) for T in fx["round_transforms_zyx_um"]]
