@@ -296,3 +296,35 @@ def test_codec_round_trips_property():
             assert np.array_equal(ref_frame, frame)          # same container bytes from both writers
 
     run()
+
+
+def test_write_behind_without_a_device_stays_synchronous_and_lazy_fallbacks_do_not_read(tmp_path, monkeypatch):
+    """Round 4.  (a) ``write_behind=True`` needs a device (the queue holds HBM tensors); without one the store writes
+    synchronously as before - nothing pending, nothing resident, files on disk when ``save`` returns.  (b) The
+    deconvolved-else-corrected fallback of ``load_local_readout_image`` / ``load_local_fiducial_image`` must not READ
+    the corrected image when a deconvolved one exists (round 3 evaluated ``get(k, fallback)`` eagerly: on a disk
+    store every decode of a bit read 0.5 GB it did not need)."""
+    from pathlib import Path
+
+    from helpers import codebook_frame
+
+    ds = pkg("datastore")
+    store = ds.ZarrImageDataStore(tmp_path / "qi2lab", device=None, write_behind=True, num_tiles=1, num_rounds=1,
+                                  num_bits=2, codebook=codebook_frame(np.ones((2, 2), dtype=np.int64)))
+    assert not store._write_behind
+    img = np.arange(4 * 20 * 24, dtype=np.uint16).reshape(4, 20, 24)
+    store.set_corrected_image(img, tile=0, bit=0)
+    store.set_corrected_image(img + 1, tile=0, round=0)
+    store.save_local_deconvolved_readout_image(img * 2, tile=0, bit=0)
+    store.save_local_deconvolved_fiducial_image(img * 3, tile=0, round=0)
+    assert not store._pending_writes and not store._resident
+    assert (tmp_path / "qi2lab" / "readouts" / "tile0000" / "bit001" / "decon_data.ome.zarr" / "0" / "zarr.json").exists()
+    store.flush()                                                   # a no-op here, harmless
+    assert store.evict_tile(0) == 0
+    reads = []
+    real = store._io.read_image
+    monkeypatch.setattr(store._io, "read_image", lambda path, device=None: (reads.append(Path(path).name), real(path, device=device))[1])
+    assert np.array_equal(store.load_local_readout_image(0, bit=0, return_future=False), img * 2)
+    assert np.array_equal(store.load_local_fiducial_image(0, round=0, return_future=False), img * 3)
+    assert reads == ["decon_data", "decon_data"], reads              # the corrected images were not touched
+    assert store.load_local_readout_image(0, bit=1, return_future=False) is None   # nothing stored for that bit
