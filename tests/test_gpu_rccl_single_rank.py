@@ -61,3 +61,25 @@ def test_bench_config3_small_through_the_rccl_group():
     assert rec["registration"]["max_shift_error_px"] < 0.35     # the reference's own tolerance (+-0.35 px)
     assert rec["transcripts_rank0"] > 0 and rec["value"] > 0
     assert rec["roofline"]["frac"] > 0
+
+
+def test_bench_config3_small_out_of_and_back_into_a_datastore_directory():
+    """``bench.py --store disk`` (round 4) at rehearsal size, through the one-rank RCCL group: every tile's images come
+    from and go back to an on-disk qi2lab datastore with read-ahead and write-behind under the compute; the record says
+    what the main thread waited for, what the I/O threads did, and that what is on disk is what was computed."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "config3_small", "--tiles", "3",
+                        "--gpus", "1", "--no-cpu-baseline", "--store", "disk", "--io-read-threads", "2",
+                        "--io-write-threads", "4"],
+                       env=_env(M3D_BENCH_FORCE_DIST="1", M3D_DIST_SINGLE_RANK="1", M3D_BENCH_WALL_S="600"),
+                       capture_output=True, text=True, timeout=1200, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["config"]["tiles_timed"] == 3 and rec["steps"] == 3 and rec["transcripts_rank0"] > 0
+    st = rec["store"]
+    assert st["round_trip_equal"] is True
+    assert st["io_threads"] == {"read_ahead_zstd": 2, "write_behind_zstd": 4, "python_io_threads": 2}
+    assert st["value_including_io"] == rec["value"] and st["value_compute_only"] >= st["value_including_io"]
+    assert st["per_tile_counts"]["images_read"] >= 8 + 16 + 16          # 8 fiducial + 16 readout + 16 predictor images
+    assert st["per_tile_counts"]["images_written"] >= 8 + 16            # deconvolved fiducials and readouts
+    assert set(st["caller_wait_s_per_tile"]) <= {"read_wait", "write_wait"}
+    assert rec["registration"]["all_ranks"] == {"calls": 3 * 7, "off_by_more_than_px": 0.35, "rounds_off": 0}
