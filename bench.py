@@ -16,6 +16,16 @@ deconvolutions, 10 x ``register_pair_to_fixed`` against round 1, 22 readout deco
 strong scaling.  Tiles are synthesised outside the timed regions (one region per tile, device-synchronised
 on both sides), so the inputs are resident in HBM whenever the clock runs.
 
+``--store disk`` (round 4; SURVEY.md 8(e)'s strong-scaling risk measured on one GPU): the tiles live in an on-disk qi2lab
+datastore (tmpfs if the box has one, a directory per rank).  Per tile the timed region then reads the fiducial, readout
+and predictor images (read-ahead of tile t + 1 under tile t's kernels) and writes the deconvolved volumes and the
+transcript table (write-behind), on ``--io-read-threads`` + ``--io-write-threads`` zstd threads.  In this mode ``value`` IS
+the wall-clock rate including every wait for I/O and the final drain of the write queue; the JSON's ``store`` object
+repeats it as ``value_including_io`` next to ``value_compute_only`` (the main thread's I/O waits subtracted),
+``caller_wait_s_per_tile``, ``background_s_per_tile``, ``host_cpu_s_per_tile`` (process CPU time), ``io_threads`` and
+``round_trip_equal`` (a volume read back from disk equals what was computed).  The HBM-resident figure to hold it
+against is the same command without ``--store disk`` (61.6 s against 61.2 s per tile).
+
     python bench.py --gpus 1 --steps 20 --warmup 5
     python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
