@@ -47,9 +47,19 @@ struct BinomRow {
     uint32_t len;  // thresholds below 2^63 - 1; the rest of the row holds 2^64 - 1
 };
 
+// A guide for the SMALL rows (q = 2 .. kBinomGuideQHi: counts of 128 to 64 (kBinomGuideQHi + 1) - 1, the table draws of
+// a dim image), small enough to sit in LDS next to a kernel's own buffers: 256 cells per row over the top eight bits of
+// v, a cell = g0 | min(g1 - g0, 3) << 12 with g0 = #{thresholds <= the cell's lower end}, g1 the same count at the next
+// cell's lower end (the row's length after the last cell).  For a v inside the cell, g0 <= D <= g1.
+constexpr uint32_t kBinomGuideQLo = 2, kBinomGuideQHi = 8;
+constexpr int kBinomGuideBits = 8;
+constexpr uint32_t kBinomGuideCells = 1u << kBinomGuideBits;
+constexpr uint32_t kBinomGuideEntries = (kBinomGuideQHi - kBinomGuideQLo + 1) * kBinomGuideCells;  // 1792 x 2 B = 3.5 KB
+
 struct BinomTables {  // a view; host or device pointers
     const uint64_t *thr;
-    const BinomRow *rows;  // [kBinomQMax + 1], rows 0 and 1 empty
+    const BinomRow *rows;     // [kBinomQMax + 1], rows 0 and 1 empty
+    const uint16_t *guide;    // [kBinomGuideEntries], device copies only (global memory; kernels stage it into LDS)
 };
 
 struct BinomPair {
@@ -114,11 +124,34 @@ M3D_HD float binom_sigma(float q)  // 4 sqrt(q)
 #endif
 }
 
-// Binomial(64 q, 1/2), 2 <= q <= kBinomQMax, from the 64-bit uniform (hi:lo).
-M3D_HD uint32_t binom_table_draw(uint32_t q, uint32_t hi, uint32_t lo, const BinomTables &t)
+// Binomial(64 q, 1/2), 2 <= q <= kBinomQMax, from the 64-bit uniform (hi:lo).  `lds_guide` (device, optional): the
+// small rows' guide staged in LDS by the calling kernel - the search then starts from the cell of v's top eight bits
+// instead of the arithmetic quantile (a logarithm, two square roots, two reciprocals, a degree-12 polynomial: 50 of the
+// draw's 75 vector instructions).  The cell brackets D between g0 and g1: equal - D is known without a threshold; one or
+// two apart - the thresholds g0 and g0 + 1 (one 16-byte load) decide, and a threshold past g1 lies above the cell and so
+// above v, no masking needed; wider cells (the far tails) and rows above kBinomGuideQHi take the arithmetic route.  The
+// exact integers decide every draw either way.  (A guide in GLOBAL memory was measured in round 4 and lost on bright
+// images - 64 lanes, 64 cache lines; LDS has no lines.  profiles/r04_split_chain.txt)
+M3D_HD uint32_t binom_table_draw(uint32_t q, uint32_t hi, uint32_t lo, const BinomTables &t,
+                                 const uint16_t *lds_guide = nullptr)
 {
     const uint64_t u = ((uint64_t)hi << 32) | lo;
     const uint64_t v = u >> 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lds_guide && q <= kBinomGuideQHi) {
+        const uint32_t cell = lds_guide[(q - kBinomGuideQLo) * kBinomGuideCells + (hi >> (32 - kBinomGuideBits))];
+        const uint32_t g0 = cell & 0xFFFu, spread = cell >> 12;
+        if (spread <= 2u) {
+            uint32_t d = g0;
+            if (spread != 0u) {
+                const BinomPair p = binom_load_pair(t.thr + (size_t)q * kBinomRowStride + 1 + g0);  // thresholds g0, g0 + 1
+                d += (p.below <= v ? 1u : 0u) + (p.above <= v ? 1u : 0u);
+            }
+            const uint32_t m = 32u * q;
+            return (u & 1u) ? m + d : m - d;
+        }
+    }
+#endif
     // the upper tail mass 1 - P(D <= d) that v leaves, from the top 32 of its 63 bits (tails below 2^-33 start
     // the search in the wrong place and fall through to the bisection)
     const float tail = ((float)(0x7FFFFFFFu - (hi >> 1)) + 0.5f) * 0x1p-31f;
@@ -145,7 +178,8 @@ M3D_HD uint32_t binom_table_draw(uint32_t q, uint32_t hi, uint32_t lo, const Bin
 // Exact Binomial(n, 1/2) for voxel `voxel` at `iteration`.  kChunked = false: n < 65536 (uint16 images), one Philox
 // block and at most one table draw; kChunked = true: any n, further chunks of 64 * 1023 from blocks 1, 2, ...
 template <bool kChunked>
-M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, uint64_t seed, const BinomTables &t)
+M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, uint64_t seed, const BinomTables &t,
+                              const uint16_t *lds_guide = nullptr)
 {
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     U32x4 c = {(uint32_t)voxel, (uint32_t)(voxel >> 32), iteration, 0u};
@@ -163,7 +197,7 @@ M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, ui
     const uint32_t q0 = q < kBinomQMax ? q : kBinomQMax;
     const uint32_t ones = (uint32_t)(popc32(r.z) + popc32(r.w));
     if (q0 >= 2u)
-        acc += binom_table_draw(q0, r.z, r.w, t);
+        acc += binom_table_draw(q0, r.z, r.w, t, lds_guide);
     else if (q0 == 1u)
         acc += ones;
     if (kChunked) {
@@ -175,7 +209,7 @@ M3D_HD uint32_t binomial_half(uint32_t n, uint64_t voxel, uint32_t iteration, ui
                 r = philox4x32<kSplitRounds>(c, k0, k1);
             }
             const uint32_t hi = (j & 1u) ? r.x : r.z, lo = (j & 1u) ? r.y : r.w;
-            acc += qc == 1u ? (uint32_t)(popc32(hi) + popc32(lo)) : binom_table_draw(qc, hi, lo, t);
+            acc += qc == 1u ? (uint32_t)(popc32(hi) + popc32(lo)) : binom_table_draw(qc, hi, lo, t, lds_guide);
             q -= qc;
         }
     }
@@ -232,8 +266,10 @@ inline uint64_t top_after_128(const U256 &a) { return a.w[3] ? ~0ull : a.w[2]; }
 struct BinomTablesHost {
     std::vector<uint64_t> thr;
     std::vector<BinomRow> rows;
+    std::vector<uint16_t> guide;  // [kBinomGuideEntries], derived from thr (see BinomTables)
     bool certified = false;  // every threshold's error interval fell inside one integer
-    BinomTables view() const { return BinomTables{thr.data(), rows.data()}; }
+    // (the host searches with the arithmetic guess; the guide is a device short cut to the same integer)
+    BinomTables view() const { return BinomTables{thr.data(), rows.data(), nullptr}; }
 };
 
 // Fixed point: x = floor(X * 2^191) for a probability X; thresholds are (sum >> 128).
@@ -281,6 +317,28 @@ inline BinomTablesHost binom_tables_build()
             dst[1 + count++] = lo;
         }
         row.len = count;
+    }
+    // the small rows' guide: counts of thresholds at the cells' lower ends, from the certified integers
+    out.guide.assign(kBinomGuideEntries, 0);
+    for (uint32_t q = kBinomGuideQLo; q <= kBinomGuideQHi; ++q) {
+        const uint64_t *T = out.thr.data() + out.rows[q].off + 1;  // threshold i at T[i]
+        const uint32_t len = out.rows[q].len;
+        uint16_t *g = out.guide.data() + (size_t)(q - kBinomGuideQLo) * kBinomGuideCells;
+        uint32_t count = 0, prev = 0;  // #{thresholds <= lower end of cell k}: monotone in k
+        for (uint32_t k = 0; k <= kBinomGuideCells; ++k) {
+            uint32_t c = len;
+            if (k < kBinomGuideCells) {
+                const uint64_t lo_end = (uint64_t)k << (63 - kBinomGuideBits);
+                while (count < len && T[count] <= lo_end) ++count;
+                c = count;
+            }
+            if (k > 0) {
+                const uint32_t spread = c - prev;
+                if (prev > 0xFFFu) ok = false;
+                g[k - 1] = (uint16_t)((prev & 0xFFFu) | ((spread < 3u ? spread : 3u) << 12));
+            }
+            prev = c;
+        }
     }
     out.certified = ok;
     return out;

@@ -1366,9 +1366,16 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
     static_assert(NS == 0 || (NS == 2187 && R == 9), "static geometry: 2187 = 9 * 9 * 3 * 9");
     extern __shared__ float2 lds_sp[];
     __shared__ double smd[5][7];
+    // the sampler's guide for the rows of dim voxels (128 to 575 counts), 3.5 KB: four workgroups of 34.2 + 3.8 KB still
+    // share a CU's 160 KB.  Filled here, visible after the barrier behind the spectrum merge.
+    __shared__ uint16_t lguide[m3d::kBinomGuideEntries];
     const ConvGeo g = static_geo<NS>(g_);
     const int N = NS ? NS : g.Xp, S = N / R, I = S / 2 + 1;
     const int tid = threadIdx.x, nt = NS ? 256 : (int)blockDim.x;
+    static_assert(m3d::kBinomGuideEntries % 8 == 0, "staged in 16-byte pieces");
+    if (!sa.injected)
+        for (int i = tid; i < (int)m3d::kBinomGuideEntries / 8; i += nt)
+            ((uint4 *)lguide)[i] = ((const uint4 *)sa.tables.guide)[i];
     const int y_hi = g.out.y0 + g.out.ny, x_hi = g.out.x0 + g.out.nx;
     const int yg0 = (g.out.y0 / 4) * 4;  // the pairing of the other X passes (four rows per group, pairs inside)
     const int pairs = (y_hi - yg0 + 1) / 2;
@@ -1470,7 +1477,7 @@ __global__ __launch_bounds__(NS ? 256 : 320, 4) void k_x_inverse_split_chain(flo
                         n = (uint32_t)fminf(vt, 1048576.0f);  // astype(int64) truncation, rlgc.py:619
                     }
                     s1 = (float)m3d::binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + (x - g.out.x0)), iteration,
-                                                                      sa.seed, sa.tables);
+                                                                      sa.seed, sa.tables, sizeof(T) == 2 ? lguide : nullptr);
                 }
                 const float s2 = val - s1;
                 const float a = h + eps;  // kl_div, rlgc.py:401-412, as raw sums

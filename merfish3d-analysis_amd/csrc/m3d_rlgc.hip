@@ -557,9 +557,14 @@ __global__ void k_debug_table_draw(const uint32_t *__restrict__ q, const uint32_
                                    const uint32_t *__restrict__ lo, int64_t n, BinomTables tables,
                                    uint32_t *__restrict__ out)
 {
+    // the small rows' guide staged in LDS, as the fused split kernel does: rows 2 .. kBinomGuideQHi take the guide route,
+    // the others the arithmetic one - tests/test_gpu_rlgc.py probes on, below and above every threshold of both kinds
+    __shared__ uint16_t lg[kBinomGuideEntries];
+    for (uint32_t i = threadIdx.x; i < kBinomGuideEntries; i += blockDim.x) lg[i] = tables.guide[i];
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = binom_table_draw(q[i], hi[i], lo[i], tables);
+        out[i] = binom_table_draw(q[i], hi[i], lo[i], tables, lg);
 }
 
 __global__ void k_clip_u16(const float *__restrict__ in, uint16_t *__restrict__ out, int64_t n)
@@ -601,17 +606,21 @@ int device_binom_tables(BinomTables *out, const void *on = nullptr)
         }
         uint64_t *thr = nullptr;
         BinomRow *rows = nullptr;
+        uint16_t *guide = nullptr;
         hipError_t e = hipMalloc(&thr, h.thr.size() * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMalloc(&rows, h.rows.size() * sizeof(BinomRow));
+        if (e == hipSuccess) e = hipMalloc(&guide, h.guide.size() * sizeof(uint16_t));
         if (e == hipSuccess) e = hipMemcpy(thr, h.thr.data(), h.thr.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(rows, h.rows.data(), h.rows.size() * sizeof(BinomRow), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(guide, h.guide.data(), h.guide.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) {  // nothing half-made stays behind
             if (thr) (void)hipFree(thr);
             if (rows) (void)hipFree(rows);
+            if (guide) (void)hipFree(guide);
             set_err("binomial split tables", hipGetErrorString(e));
             return e == hipErrorOutOfMemory ? M3D_ERR_OUT_OF_MEMORY : M3D_ERR_HIP;
         }
-        per_device[dev] = BinomTables{thr, rows};
+        per_device[dev] = BinomTables{thr, rows, guide};
     }
     *out = per_device[dev];
     return M3D_OK;
