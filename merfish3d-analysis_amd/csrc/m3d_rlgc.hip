@@ -216,6 +216,15 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
                               const float *__restrict__ injected, KlPartial *__restrict__ partial)
 {
     __shared__ double sm[4];
+    // the sampler's guide for the rows of dim voxels, staged in LDS (m3d_binom.h; uint16 images: float images keep the
+    // arithmetic route of their chunked draws)
+    __shared__ uint16_t lguide[kBinomGuideEntries];
+    const bool use_guide = sizeof(T) == 2 && !injected;
+    if (use_guide) {
+        for (uint32_t i = threadIdx.y * blockDim.x + threadIdx.x; i < kBinomGuideEntries; i += blockDim.x * blockDim.y)
+            lguide[i] = tables.guide[i];
+        __syncthreads();
+    }
     const float eps = 1e-4f;
     // per-thread partial sums in float32 (<= a few hundred terms each), promoted to double
     // for the cross-thread reduction: keeps the kernel HBM-bound instead of f64-VALU-bound
@@ -254,7 +263,8 @@ __global__ void k_split_ratio(const float *__restrict__ hu, const T *__restrict_
                     // the draw only (bounds the chunk loop; u16 data never reaches it)
                     const uint32_t n = (uint32_t)fminf(vt, 1048576.0f);
                     // a uint16 count needs one Philox block and one table row at most
-                    s1 = (float)binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + x), iteration, seed, tables);
+                    s1 = (float)binomial_half<!(sizeof(T) == 2)>(n, (uint64_t)(irow + x), iteration, seed, tables,
+                                                                 use_guide ? lguide : nullptr);
                 }
                 const float s2 = v - s1;
                 // kl_div, rlgc.py:401-412, as raw sums (normalisers applied on the host)
