@@ -13,10 +13,12 @@ import csv, sys, re, glob, json
 tag, pat = sys.argv[1], sys.argv[2]
 d = json.loads([l for l in open('/tmp/abb_out.txt') if l.startswith('{')][-1])
 f = glob.glob('/tmp/abb_prof/**/p_kernel_stats.csv', recursive=True)[0]
-hits = []
+hits = []; tot = 0.0; n_it = 0
 for r in csv.DictReader(open(f)):
     m = re.search(r"(k_\w+(?:<[^>]*>)?)", r["Name"])
+    if m and re.search(r"k_(x_|y_|z_|kl_|fused_fin)", m.group(1)): tot += float(r["TotalDurationNs"]) / 1e6
+    if m and "split_chain" in m.group(1): n_it = int(r["Calls"])
     if m and re.search(pat, m.group(1)): hits.append(f"{m.group(1)[:40]} x{r['Calls']} avg {float(r['AverageNs'])/1e3:8.1f} us")
-print(f"== {tag:8s} value {d['value']} frac {d['roofline']['frac']} | " + " | ".join(hits))
+print(f"== {tag:8s} value {d['value']} frac {d['roofline']['frac']} iteration kernels {tot / max(n_it, 1):.3f} ms | " + " | ".join(hits))
 PY
 done
