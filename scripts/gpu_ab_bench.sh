@@ -19,6 +19,8 @@ for r in csv.DictReader(open(f)):
     if m and re.search(r"k_(x_|y_|z_|kl_|fused_fin)", m.group(1)): tot += float(r["TotalDurationNs"]) / 1e6
     if m and "split_chain" in m.group(1): n_it = int(r["Calls"])
     if m and re.search(pat, m.group(1)): hits.append(f"{m.group(1)[:40]} x{r['Calls']} avg {float(r['AverageNs'])/1e3:8.1f} us")
+wp = d.get("workspace_placement", {}).get("candidates_ms_rank0")
+if wp: print(f"   {tag:8s} workspace candidates {wp}")
 print(f"== {tag:8s} value {d['value']} frac {d['roofline']['frac']} iteration kernels {tot / max(n_it, 1):.3f} ms | " + " | ".join(hits))
 PY
 done

@@ -11,6 +11,9 @@ Z, Y, X = (int(v) for v in sys.argv[1:4])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
+# M3D_PROBE_PREALLOC_GB: hold that much HBM in 1-GiB tensors before the plan's workspace is allocated (the bench's state)
+ballast = [torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+           for _ in range(int(__import__("os").environ.get("M3D_PROBE_PREALLOC_GB", "0")))]
 if __import__("os").environ.get("M3D_PROBE_IMAGE", "noise") == "emitters":
     # the bench's kind of image: background 100, blurred point emitters of 300-900 peak counts, shot noise
     kernels = importlib.import_module("merfish3d-analysis_amd.kernels")
@@ -31,6 +34,9 @@ t0 = time.time()
 out, info = rl.rlgc_device(img, psf, max_iterations=1)
 torch.cuda.synchronize()
 print(f"first call (plan + 1 iter): {time.time() - t0:.2f}s padded={info.padded_shape}", flush=True)
+# M3D_PROBE_POSTALLOC_GB: the same ballast, but allocated AFTER the plan's workspace
+ballast += [torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+            for _ in range(int(__import__("os").environ.get("M3D_PROBE_POSTALLOC_GB", "0")))]
 for n in (iters, 2 * iters):
     torch.cuda.synchronize()
     t0 = time.time()
