@@ -26,6 +26,10 @@ repeats it as ``value_including_io`` next to ``value_compute_only`` (the main th
 ``round_trip_equal`` (a volume read back from disk equals what was computed).  The HBM-resident figure to hold it
 against is the same command without ``--store disk`` (61.6 s against 61.2 s per tile).
 
+``card_state_rank0`` (diagnostic): shader / memory clock, board power and temperatures of rank 0's card sampled from its
+hwmon files every two seconds while the steps run.  The workload holds the card at its power limit and the shader clock
+is what the firmware gives way with - it explains the +-1.5 % between runs of the same tree.
+
     python bench.py --gpus 1 --steps 20 --warmup 5
     python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -351,6 +355,73 @@ def _free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return int(s.getsockname()[1])
+
+
+class CardState:
+    """Clocks, board power and temperatures of one card while the timed region runs - a diagnostic next to ``value``,
+    not part of it.  The card runs this workload AT ITS POWER LIMIT (about 1 350 W: the shader clock sits near 2.1 of
+    2.4 GHz), and a single run carries +-1.5 % from one process to the next (``profiles/r04_workspace_placement.txt``);
+    these numbers say which state a run met.  Plain reads of the amdgpu hwmon files of the card's PCI function every
+    two seconds from a host thread (``rocm-smi`` reads the same files); any failure leaves the record out."""
+
+    FILES = {"sclk_mhz": ("freq1_input", 1e-6), "mclk_mhz": ("freq2_input", 1e-6), "power_w": ("power1_input", 1e-6),
+             "junction_c": ("temp2_input", 1e-3), "hbm_c": ("temp3_input", 1e-3)}
+
+    def __init__(self, hwmon_dir, period_s: float = 2.0):
+        import threading
+
+        self.dir = Path(hwmon_dir) if hwmon_dir else None
+        self.period = period_s
+        self.samples: dict = {k: [] for k in self.FILES}
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.dir else None
+
+    @staticmethod
+    def hwmon_of(device_index: int, sysfs: str = "/sys/bus/pci/devices"):
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            fn = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            found = sorted(Path(sysfs, fn, "hwmon").glob("hwmon*"))
+            return found[0] if found else None
+        except Exception:
+            return None
+
+    def _read(self, name: str, scale: float):
+        try:
+            return float((self.dir / name).read_text()) * scale
+        except (OSError, ValueError):
+            return None
+
+    def _run(self) -> None:
+        while not self._stop.wait(self.period):
+            for key, (name, scale) in self.FILES.items():
+                v = self._read(name, scale)
+                if v is not None:
+                    self.samples[key].append(v)
+
+    def start(self) -> "CardState":
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def stop(self) -> None:
+        if self._thread and self._thread.is_alive():
+            self._stop.set()
+            self._thread.join(timeout=5.0)
+
+    def summary(self):
+        """-> {"sclk_mhz": {"mean", "min", "max"}, ..., "power_cap_w", "samples"} of the samples so far, or None."""
+        if not self._thread:
+            return None
+        out = {k: {"mean": round(float(np.mean(v)), 1), "min": round(min(v), 1), "max": round(max(v), 1)}
+               for k, v in ((k, list(v)) for k, v in self.samples.items()) if v}
+        if not out:
+            return None
+        cap = self._read("power1_cap", 1e-6)
+        if cap is not None:
+            out["power_cap_w"] = round(cap, 1)
+        out["samples"] = max(len(v) for v in self.samples.values())
+        return out
 
 
 def visible_gpu_count() -> int | None:
@@ -942,6 +1013,7 @@ def main() -> int:
             "unit": "Mvoxels/s",
         }
 
+    card = CardState(CardState.hwmon_of(gpu_index) if rank == 0 else None).start()
     for i in range(n_steps):
         if strong:
             mine = i < len(my_tiles)
@@ -979,6 +1051,7 @@ def main() -> int:
         if rank == 0:
             if disk:
                 extras["store"] = io_record(elapsed, int(tiles_all))
+            extras["card_state_rank0"] = card.summary()
             last = record(steps_done, warm_done, elapsed, total_iters, int(tiles_all))
             print(json.dumps(last), flush=True)
         # the measured step time replaces the warm-up estimate; stop (on every rank) if the next step would
@@ -988,6 +1061,7 @@ def main() -> int:
         if stop and i + 1 < n_steps:
             progress(f"stopping after {steps_done} timed step(s): wall budget")
             break
+    card.stop()
     if disk:
         # the writes still queued behind the last tile belong to the job: drain them inside the clock
         sync()

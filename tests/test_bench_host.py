@@ -90,3 +90,36 @@ def test_visible_gpu_count_takes_the_smallest_claim_and_admits_ignorance(monkeyp
     assert bench.visible_gpu_count() == 2
     monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "")
     assert bench.visible_gpu_count() == 0
+
+
+def test_card_state_sampler_reads_the_hwmon_files_and_survives_their_absence(bench, tmp_path):
+    """The diagnostic next to ``value`` (clocks, board power, temperatures while the timed region runs): amdgpu's hwmon
+    units, a running summary, and no record - not an error - where the files are missing."""
+    import time
+
+    hw = tmp_path / "hwmon3"
+    hw.mkdir()
+    for name, raw in {"freq1_input": 2140000000, "freq2_input": 2000000000, "power1_input": 1350000000,
+                      "power1_cap": 1400000000, "temp2_input": 56000, "temp3_input": 70000}.items():
+        (hw / name).write_text(f"{raw}\n")
+    card = bench.CardState(hw, period_s=0.02).start()
+    time.sleep(0.2)
+    (hw / "freq1_input").write_text("1900000000\n")
+    time.sleep(0.2)
+    running = card.summary()          # usable while the sampler runs (one JSON line per timed step)
+    card.stop()
+    got = card.summary()
+    assert running["samples"] >= 2 and got["samples"] >= running["samples"]
+    assert got["sclk_mhz"]["max"] == 2140.0 and got["sclk_mhz"]["min"] == 1900.0
+    assert got["mclk_mhz"]["mean"] == 2000.0 and got["power_w"]["mean"] == 1350.0 and got["power_cap_w"] == 1400.0
+    assert got["junction_c"]["max"] == 56.0 and got["hbm_c"]["max"] == 70.0
+
+    (hw / "temp3_input").unlink()     # a file that a kernel version does not have: the others are still reported
+    partial = bench.CardState(hw, period_s=0.02).start()
+    time.sleep(0.1)
+    partial.stop()
+    assert "hbm_c" not in partial.summary() and "sclk_mhz" in partial.summary()
+    nothing = bench.CardState(None).start()
+    nothing.stop()
+    assert nothing.summary() is None
+    assert bench.CardState.hwmon_of(0, sysfs=str(tmp_path / "no_such_sysfs")) is None
