@@ -1618,7 +1618,10 @@ __device__ __forceinline__ void y_stage_static(float2 *data, const float2 *__res
     // Requesting the three radix-9 stages' twiddles at kernel start, in front of the tile's loads (18 registers), moved
     // nothing either (643 vs 650 us forward, 500 vs 480 us mirror, inverse 705 vs 704 us with one column per item): the Y
     // pass does not wait for its table loads.
-    constexpr int CPT = (TWc % CPT_ == 0) ? CPT_ : 1, GR = TWc / CPT;
+    // Radix 27 (the last forward / first inverse stage of 2187 = 9 * 9 * 27): blocks of 27 elements, every twiddle is 1;
+    // 54 registers of data per column, so one column per item.
+    static_assert(R != 27 || sub == 1, "radix 27 only as the twiddle-free stage of block size 27");
+    constexpr int CPT = (TWc % CPT_ == 0 && R != 27) ? CPT_ : 1, GR = TWc / CPT;
 #pragma unroll 1
     for (int t = tid; t < per_fft * GR; t += NT_) {
         const int c = (t % GR) * CPT, it = t / GR;
@@ -1725,9 +1728,12 @@ __global__ __launch_bounds__(NT_) void k_y_pass_static(float2 *__restrict__ spec
     }
     __syncthreads();
     if (!INV) {
-        y_stage_static<R0, false, YP, YP, TWc, NT_>(lds_ys, tw, tid);
+        // two columns per item in the forward radix-9 stages where the registers are there anyway (9 * 9 * 27: the
+        // radix-27 stage sets the kernel's 70; forward 592 -> 583 us) - elsewhere they cost the second block per CU
+        constexpr int FC = R2 == 27 ? 2 : 1;
+        y_stage_static<R0, false, YP, YP, TWc, NT_, FC>(lds_ys, tw, tid);
         __syncthreads();
-        y_stage_static<R1, false, YP, YP / R0, TWc, NT_>(lds_ys, tw, tid);
+        y_stage_static<R1, false, YP, YP / R0, TWc, NT_, FC>(lds_ys, tw, tid);
         __syncthreads();
         y_stage_static<R2, false, YP, YP / (R0 * R1), TWc, NT_>(lds_ys, tw, tid);
         __syncthreads();
@@ -2301,6 +2307,18 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
     // the static Y kernels spread (butterfly, column group) items over the threads: 972 (forward) / 486 (inverse) items
     // in the radix-9 stages, one round with 1024 threads (two blocks of 16 waves fill a CU); the generic kernels keep 768
     if (p->ystatic) p->ythreads = 1024;
+    // The headline length runs as 9 * 9 * 27 (round 4): the radix-3 stage and the radix-9 stage in front of it become
+    // one radix-27 butterfly on blocks of 27 - no twiddles, 54 registers of data - which takes one of the pass's four
+    // trips through LDS away: inverse 670 -> 640 us, forward 621 -> 593 us per launch on one box
+    // (profiles/r04_workspace_placement.txt section 10; the passes hold the card at its power limit, section 8).  70
+    // registers: two blocks of 768 threads per CU.  Static kernels only - the run-time kernels have no radix-27 stage.
+    if (p->ystatic == 2187) {
+        p->ythreads = 768;
+        p->ay.nstages = 3;
+        p->ay.radix[0] = 9;
+        p->ay.radix[1] = 9;
+        p->ay.radix[2] = 27;
+    }
     // 2592 (2304-pixel sensors): tiles of two columns (41.5 KB, three workgroups per CU), 9 9 8 4, 640 threads - the 576
     // (butterfly, column) items of a radix-9 stage in one round, 3 x 640 threads per CU
     if (!p->ystatic && knob("M3D_FFT_YSTATIC", 1) && Yp == 2592 && p->TW == 2 && p->lch == 7 && p->gy == 4) {
@@ -2384,14 +2402,10 @@ int fftconv_create(int Zp, int Yp, int Xp, FftConvPlan **out)
             rc = M3D_ERR_HIP;
         }
     };
-    if (p->ystatic == 2187 && p->ythreads == 1024) {
-        allow((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 1024>);
-        allow((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 1024>);
-        allow((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 1024>);
-    } else if (p->ystatic == 2187) {
-        allow((const void *)k_y_forward_mirror_static<2187, 9, 9, 9, 3, 7, 768>);
-        allow((const void *)k_y_pass_static<false, 2187, 9, 9, 9, 3, 7, 768>);
-        allow((const void *)k_y_pass_static<true, 2187, 9, 9, 9, 3, 7, 768>);
+    if (p->ystatic == 2187) {
+        allow((const void *)k_y_forward_mirror_static<2187, 9, 9, 27, 1, 7, 768>);
+        allow((const void *)k_y_pass_static<false, 2187, 9, 9, 27, 1, 7, 768>);
+        allow((const void *)k_y_pass_static<true, 2187, 9, 9, 27, 1, 7, 768>);
     } else if (p->ystatic && p->lds_y > kDefaultLdsLimit) {  // the other static tiles are 64 KB at most by construction
         fftconv_destroy(p);
         return M3D_ERR_UNSUPPORTED;
@@ -2498,17 +2512,14 @@ static int launch_z(const FftConvPlan *p, float2 *spec, const float2 *otf, const
     return M3D_OK;
 }
 
-// Y pass: the static-geometry build when the plan is the headline one (2187 = 9 * 9 * 9 * 3, TW 4, 128-row chunks,
-// 768 threads, four transforms per item), else the generic kernel.
+// Y pass: the static-geometry build when the plan is the headline one (2187 = 9 * 9 * 27, TW 4, 128-row chunks,
+// 768 threads), or one of the other common lengths, else the generic kernel.
 template <bool INV>
 static void launch_y_pass(const FftConvPlan *p, float2 *spec, const ConvGeo &g, int nz, hipStream_t st)
 {
     const dim3 grid((unsigned)(nz * p->nT)), block(p->ythreads);
     if (p->ystatic == 2187) {
-        if (p->ythreads == 1024)
-            hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
-        else
-            hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 9, 3, 7, 768>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
+        hipLaunchKernelGGL((k_y_pass_static<INV, 2187, 9, 9, 27, 1, 7, 768>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     } else if (p->ystatic == 2048)
         hipLaunchKernelGGL((k_y_pass_static<INV, 2048, 8, 8, 8, 4, 7, 1024>), grid, block, p->lds_y, st, spec, g, p->ay.tw);
     else if (p->ystatic == 1728)
@@ -2571,8 +2582,13 @@ static int launch_forward_xy(const FftConvPlan *p, const float *src, float2 *spe
 #define M3D_LAUNCH_YMS(YP, R0, R1, R2, R3, NT)                                                                          \
     hipLaunchKernelGGL((k_y_forward_mirror_static<YP, R0, R1, R2, R3, 7, NT>), dim3(yplanes * (unsigned)p->nT),           \
                        dim3(p->ythreads), p->lds_y, st, spec, spec_alt, g, p->ay.tw)
-        if (p->ystatic == 2187 && one_reflection && p->ythreads == 1024) M3D_LAUNCH_YMS(2187, 9, 9, 9, 3, 1024);
-        else if (p->ystatic == 2187 && one_reflection) M3D_LAUNCH_YMS(2187, 9, 9, 9, 3, 768);
+        if (p->ystatic == 2187 && !one_reflection) {
+            // 9 * 9 * 27 exists as static kernels only (the run-time kernels have no radix-27 stage), and a pad deeper
+            // than the core cannot occur at this length: 2187 is chosen for images of 1945 rows and more
+            set_err("fftconv", "a symmetric pad deeper than the image at padded length 2187");
+            return M3D_ERR_UNSUPPORTED;
+        }
+        if (p->ystatic == 2187) M3D_LAUNCH_YMS(2187, 9, 9, 27, 1, 768);
         else if (p->ystatic == 2048 && one_reflection) M3D_LAUNCH_YMS(2048, 8, 8, 8, 4, 1024);
         else if (p->ystatic == 1728 && one_reflection) M3D_LAUNCH_YMS(1728, 9, 8, 8, 3, 1024);
         else if (p->ystatic == 1296 && one_reflection) M3D_LAUNCH_YMS(1296, 9, 9, 4, 4, 1024);

@@ -2,7 +2,7 @@
 
 BASELINE.json configs[1] pads a 64 x 2048 x 2048 tile to 128 x 2187 x 2187, and at 2187 = 9 * 9 * 9 * 3 the plan
 selects kernels compiled for that geometry alone (`k_x_forward_reg<1, 2187>`, `k_x_inverse_split_chain<..., 2187>`,
-`k_x_inverse_dual_reg<1, true, 2187>`, `k_x_inverse_reg<1, 2, 2187, true>`, `k_y_pass_static<..., 2187, 9, 9, 9, 3>`,
+`k_x_inverse_dual_reg<1, true, 2187>`, `k_x_inverse_reg<1, 2, 2187, true>`, `k_y_pass_static<..., 2187, 9, 9, 27, 1>`,
 `k_y_forward_mirror_static<2187, ...>`): literal stages, register twiddles, chained tails, a radix list that exists
 nowhere else.  Until round 4 they were compared with the run-time-geometry kernels only (which meet the oracle at other
 lengths).  Here the NumPy restatement (oracle/rlgc_ref.py, pinned bit for bit by the reference-run goldens) is the
