@@ -27,7 +27,9 @@ repeats it as ``value_including_io`` next to ``value_compute_only`` (the main th
 against is the same command without ``--store disk`` (61.6 s against 61.2 s per tile).
 
 ``card_state_rank0`` (diagnostic): shader / memory clock, board power and temperatures of rank 0's card sampled from its
-hwmon files every two seconds while the steps run.  The workload holds the card at its power limit and the shader clock
+hwmon files every two seconds while the steps run; with more than one rank ``card_state_all_ranks`` adds the lowest and
+highest mean clock, power and HBM temperature over the ranks' cards (the max-over-ranks rule makes the slowest card's
+clock the job's).  The workload holds the card at its power limit and the shader clock
 is what the firmware gives way with - it explains the +-1.5 % between runs of the same tree.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -276,6 +278,34 @@ def aggregate_over_ranks(elapsed: float, iters: float, world: int, device) -> tu
     it = torch.tensor([iters], dtype=torch.float64, device=device)
     dist.all_reduce(it, op=dist.ReduceOp.SUM)
     return float(t.item()), float(it.item())
+
+
+def card_state_over_ranks(summary, world: int, device):
+    """The ranks' card states side by side: lowest and highest mean shader clock, board power and HBM temperature over
+    the ranks (a rank without a record counts for nothing) - the max-over-ranks timing rule makes the slowest card's
+    clock the job's.  Collective: every rank calls it."""
+    keys = ("sclk_mhz", "power_w", "hbm_c")
+    mine = [float(summary[k]["mean"]) if summary and k in summary else float("nan") for k in keys]
+    if world <= 1 and not _process_group_live():
+        lo, hi, n = mine, mine, 1 if summary else 0
+    else:
+        import torch.distributed as dist
+
+        if dist.get_backend() != "nccl":
+            device = torch.device("cpu")
+        have = 0.0 if any(v != v for v in mine) else 1.0
+        big = 1e30
+        t_lo = torch.tensor([v if have else big for v in mine], dtype=torch.float64, device=device)
+        t_hi = torch.tensor([v if have else -big for v in mine], dtype=torch.float64, device=device)
+        t_n = torch.tensor([have], dtype=torch.float64, device=device)
+        dist.all_reduce(t_lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_n, op=dist.ReduceOp.SUM)
+        lo, hi, n = t_lo.tolist(), t_hi.tolist(), int(t_n.item())
+    if not n:
+        return None
+    return {"ranks_reporting": n, **{k: {"lowest_rank_mean": round(a, 1), "highest_rank_mean": round(b, 1)}
+                                       for k, a, b in zip(keys, lo, hi)}}
 
 
 def agree_min(value: int, world: int, device) -> int:
@@ -1013,7 +1043,7 @@ def main() -> int:
             "unit": "Mvoxels/s",
         }
 
-    card = CardState(CardState.hwmon_of(gpu_index) if rank == 0 else None).start()
+    card = CardState(CardState.hwmon_of(gpu_index)).start()   # every rank samples its own card
     for i in range(n_steps):
         if strong:
             mine = i < len(my_tiles)
@@ -1048,10 +1078,12 @@ def main() -> int:
         reg_calls_all = aggregate_over_ranks(0.0, stats["reg_calls"], world, device)[1] if strong else 0.0
         extras["registration_all_ranks"] = {"calls": int(reg_calls_all), "off_by_more_than_px": MISREGISTRATION_PX,
                                             "rounds_off": int(reg_off_all)} if strong else None
+        cards_all = card_state_over_ranks(card.summary(), world, device) if world > 1 or force_dist else None
         if rank == 0:
             if disk:
                 extras["store"] = io_record(elapsed, int(tiles_all))
             extras["card_state_rank0"] = card.summary()
+            extras["card_state_all_ranks"] = cards_all
             last = record(steps_done, warm_done, elapsed, total_iters, int(tiles_all))
             print(json.dumps(last), flush=True)
         # the measured step time replaces the warm-up estimate; stop (on every rank) if the next step would

@@ -102,6 +102,12 @@ def _worker(rank, world, port, ret):
         import bench
 
         out["agg"] = bench.aggregate_over_ranks(1.0 + rank, 10.0 * (rank + 1), world, torch.device("cpu"))
+        # the ranks' card states side by side (rank 1's card the slower, hotter one); a rank without a record is left out
+        state = {"sclk_mhz": {"mean": 2140.0 - 60.0 * rank}, "power_w": {"mean": 1350.0 + 8.0 * rank},
+                 "hbm_c": {"mean": 66.0 + 5.0 * rank}}
+        out["cards"] = bench.card_state_over_ranks(state, world, torch.device("cpu"))
+        out["cards_one_missing"] = bench.card_state_over_ranks(state if rank == 0 else None, world, torch.device("cpu"))
+        out["cards_none"] = bench.card_state_over_ranks(None, world, torch.device("cpu"))
         dist.barrier()
         dist.destroy_process_group()
         ret[rank] = out
@@ -135,6 +141,14 @@ def test_two_rank_shares_pooled_statistics_and_timing():
     assert res[0]["tiles_dr"] == (tiles[:3], True) and res[1]["tiles_dr"] == (tiles[3:], True)
     assert res[0]["tiles_dr_few"] == (["only"], False) and res[1]["tiles_dr_few"] == (["only"], False)
     assert res[0]["bits_tile_parallel"] == ([bits], False) and res[1]["bits_tile_parallel"] == ([bits], False)
+    for r in range(world):
+        assert res[r]["cards"] == {"ranks_reporting": 2,
+                                   "sclk_mhz": {"lowest_rank_mean": 2080.0, "highest_rank_mean": 2140.0},
+                                   "power_w": {"lowest_rank_mean": 1350.0, "highest_rank_mean": 1358.0},
+                                   "hbm_c": {"lowest_rank_mean": 66.0, "highest_rank_mean": 71.0}}
+        assert res[r]["cards_one_missing"]["ranks_reporting"] == 1
+        assert res[r]["cards_one_missing"]["sclk_mhz"] == {"lowest_rank_mean": 2140.0, "highest_rank_mean": 2140.0}
+        assert res[r]["cards_none"] is None
     pooled = np.concatenate([np.concatenate(res[r]["local"]) for r in range(world)]).astype(np.float32)
     for r in range(world):
         assert res[r]["count"] == pooled.size
