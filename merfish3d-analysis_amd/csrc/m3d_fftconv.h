@@ -161,7 +161,7 @@ int fftconv_dual_consensus(const FftConvPlan *p, float2 *spec1, const float2 *sp
 
 // Parity hook (tests): the packed complex primitives and small butterflies of m3d_fft.h on n element triples;
 // out holds kDebugPkSlots values per element (layout in k_debug_pk).
-constexpr int kDebugPkSlots = 10 + 2 * (3 + 4 + 8 + 9);
+constexpr int kDebugPkSlots = 10 + 2 * (3 + 4 + 8 + 9 + 27);
 int fft_debug_pk(const float2 *a, const float2 *b, const float2 *c, int64_t n, float2 *out, void *stream);
 
 }  // namespace m3d

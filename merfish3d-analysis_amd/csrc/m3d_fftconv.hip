@@ -2926,6 +2926,19 @@ __global__ void k_debug_pk(const float2 *__restrict__ a, const float2 *__restric
     run([](float2 *v) { dft8<true>(v); }, 8);
     run([](float2 *v) { dft9<false>(v); }, 9);
     run([](float2 *v) { dft9<true>(v); }, 9);
+    // radix 27 (the twiddle-free stage of the 9 * 9 * 27 Y passes): the nine values and their products with B and with C
+    auto run27 = [&](auto fn) {
+        float2 v[27];
+        for (int q = 0; q < 9; ++q) {
+            v[q] = seq[q];
+            v[9 + q] = cmul(seq[q], B);
+            v[18 + q] = cmul(seq[q], C);
+        }
+        fn(v);
+        for (int q = 0; q < 27; ++q) o[at++] = v[q];
+    };
+    run27([](float2 *v) { dft27<false>(v); });
+    run27([](float2 *v) { dft27<true>(v); });
 }
 }  // namespace
 

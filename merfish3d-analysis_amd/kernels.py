@@ -152,11 +152,11 @@ def binom_debug_table_draw(q: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) 
 
 def fft_debug_pk(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
     """The packed complex primitives and small butterflies of the FFT passes on complex64 triples (parity hook):
-    returns (n, 58) complex64, layout as in ``k_debug_pk`` (csrc/m3d_fftconv.hip)."""
+    returns (n, 112) complex64, layout as in ``k_debug_pk`` (csrc/m3d_fftconv.hip)."""
     a, b, c = (t.contiguous() for t in (a, b, c))
     if not (a.dtype == b.dtype == c.dtype == torch.complex64) or not (a.shape == b.shape == c.shape) or a.dim() != 1:
         raise ValueError("a, b, c must be one-dimensional complex64 tensors of one length")
-    out = torch.empty((a.numel(), 58), dtype=torch.complex64, device=a.device)
+    out = torch.empty((a.numel(), 112), dtype=torch.complex64, device=a.device)  # kDebugPkSlots
     with torch.cuda.device(a.device):
         _hip.check(_hip.lib().m3d_fft_debug_pk(a.data_ptr(), b.data_ptr(), c.data_ptr(), a.numel(), out.data_ptr(),
                                                _stream(a)), "m3d_fft_debug_pk")

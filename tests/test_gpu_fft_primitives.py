@@ -2,7 +2,7 @@
 
 The products with +-i, the complex products and the Hermitian split / merge terms are written as single
 ``v_pk_*_f32`` instructions with explicit ``op_sel`` / ``neg`` modifiers (the compiler does not select them), so every
-form is pinned here against the arithmetic it stands for, and the 3- / 4- / 8- / 9-point butterflies built from them
+form is pinned here against the arithmetic it stands for, and the 3- / 4- / 8- / 9- / 27-point butterflies built from them
 against ``numpy.fft`` - the transform the reference's convolutions use (rlgc.py:424-436 via cupy.fft / numpy.fft)."""
 
 import numpy as np
@@ -60,4 +60,11 @@ def test_butterflies_are_dfts():
             at += radix
             scale = np.abs(full).max()       # outputs in natural order for every radix
             np.testing.assert_allclose(got, full, rtol=0, atol=4e-6 * scale, err_msg=f"radix {radix} inverse {inverse}")
+    # radix 27 - the twiddle-free last forward / first inverse stage of the 9 * 9 * 27 Y passes of the headline length
+    x27 = np.concatenate([seq, seq * b[:, None], seq * c[:, None]], axis=1)
+    for inverse in (False, True):
+        full = np.fft.ifft(x27, axis=1) * 27 if inverse else np.fft.fft(x27, axis=1)
+        got = out[:, at:at + 27]
+        at += 27
+        np.testing.assert_allclose(got, full, rtol=0, atol=6e-6 * np.abs(full).max(), err_msg=f"radix 27 inverse {inverse}")
     assert at == out.shape[1]
